@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the Python reference.
+
+Runs ONLY in the build container, where the reference checkout is mounted read-only
+at /root/reference (it never travels to the GPU box, and nothing in tests/ reads it at
+run time).  It imports the reference's own modules, drives them with seeded inputs and
+stores inputs + outputs as small .npz files.  No reference source is copied.
+
+    python tests/golden/gen_golden.py            # rewrites every fixture
+
+Canonical encodings (shared with include/inversus_hip.h and oracle/):
+  grid   : u32 words, bit (y*W + x) set <=> tile WHITE
+  player : [x, y, ammo, reload_counter, alive]
+  bullet : u16  x | y<<6 | dir<<12 | owner<<14, dir 0=UP 1=RIGHT 2=DOWN 3=LEFT, owner 0=P1 1=P2
+  obs    : np.packbits(obs.reshape(-1) != 0) -- every obs value is asserted to be 0.0 or 1.0
+"""
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("INVERSUS_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+from inversus.core import InversusEnv                                   # noqa: E402
+from inversus.game_types import TileColor, Direction, PlayerId, ActionType  # noqa: E402
+from inversus_rl import env_wrappers as ew                              # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+K = 16
+DIR_IDX = {Direction.UP: 0, Direction.RIGHT: 1, Direction.DOWN: 2, Direction.LEFT: 3}
+
+
+def grid_words(env):
+    W, H = env.width, env.height
+    words = np.zeros((W * H + 31) // 32, dtype=np.uint32)
+    for y in range(H):
+        for x in range(W):
+            if env.grid[y][x] == TileColor.WHITE:
+                i = y * W + x
+                words[i >> 5] |= np.uint32(1 << (i & 31))
+    return words
+
+
+def player_rows(env):
+    return np.array([[p.x, p.y, p.ammo, p.reload_counter, int(p.alive)]
+                     for p in (env.player1, env.player2)], dtype=np.int32)
+
+
+def bullet_words(env):
+    out = np.zeros(K, dtype=np.uint16)
+    assert len(env.bullets) <= K, "bullet bound exceeded"
+    for i, b in enumerate(env.bullets):
+        owner = 0 if b.owner == PlayerId.P1 else 1
+        out[i] = (b.x & 63) | ((b.y & 63) << 6) | (DIR_IDX[b.dir] << 12) | (owner << 14)
+    return out
+
+
+def winner_code(env):
+    w = env.get_winner()
+    return 0 if w is None else (1 if w == PlayerId.P1 else 2)
+
+
+def obs_bits(obs_grid):
+    flat = np.asarray(obs_grid).reshape(-1)
+    assert flat.dtype == np.float32
+    assert np.all((flat == 0.0) | (flat == 1.0))
+    return np.packbits(flat != 0)
+
+
+def action_stream(rng, shape, biased):
+    if not biased:
+        return rng.randint(0, 13, size=shape).astype(np.uint8)
+    a = rng.randint(0, 13, size=shape)
+    shoot = rng.randint(5, 13, size=shape)
+    pick = rng.random_sample(shape) < 0.7
+    return np.where(pick, shoot, a).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------- G1
+def gen_spawn(W, H):
+    seeds = list(range(64)) + [2 ** 31, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 7, -5, 2 ** 62 + 12345]
+    R = 4
+    pos = np.zeros((len(seeds), R, 4), np.int32)
+    grid = np.zeros((len(seeds), R, (W * H + 31) // 32), np.uint32)
+    for si, s in enumerate(seeds):
+        env = InversusEnv(width=W, height=H, seed=s)       # reset #0 happens in __init__
+        for r in range(R):
+            if r > 0:
+                env.reset()
+            pos[si, r] = (env.player1.x, env.player1.y, env.player2.x, env.player2.y)
+            grid[si, r] = grid_words(env)
+    np.savez_compressed(os.path.join(OUT, f"g1_spawn_{W}x{H}.npz"),
+                        seeds=np.array(seeds, np.int64), pos=pos, grid=grid, W=W, H=H)
+
+
+# --------------------------------------------------------------------------- G2
+def gen_core_trace(name, W, H, E, T, base_seed, act_seed, biased):
+    rng = np.random.RandomState(act_seed)
+    a1 = action_stream(rng, (T, E), biased)
+    a2 = action_stream(rng, (T, E), biased)
+    envs = [InversusEnv(width=W, height=H, seed=base_seed + i) for i in range(E)]
+    GW = (W * H + 31) // 32
+    grid = np.zeros((T, E, GW), np.uint32)
+    players = np.zeros((T, E, 2, 5), np.int32)
+    nb = np.zeros((T, E), np.int32)
+    bullets = np.zeros((T, E, K), np.uint16)
+    over = np.zeros((T, E), np.uint8)
+    winner = np.zeros((T, E), np.uint8)
+    init_players = np.stack([player_rows(e) for e in envs])
+    init_grid = np.stack([grid_words(e) for e in envs])
+    for t in range(T):
+        for i, env in enumerate(envs):
+            env.step_players(ew.discrete_to_action(int(a1[t, i])), ew.discrete_to_action(int(a2[t, i])))
+            grid[t, i] = grid_words(env)
+            players[t, i] = player_rows(env)
+            nb[t, i] = len(env.bullets)
+            bullets[t, i] = bullet_words(env)
+            over[t, i] = env.is_round_over()
+            winner[t, i] = winner_code(env)
+            if env.is_round_over():
+                env.reset()                      # training-loop style: same MT stream continues
+    np.savez_compressed(os.path.join(OUT, f"g2_core_{name}.npz"), W=W, H=H, base_seed=base_seed,
+                        a1=a1, a2=a2, grid=grid, players=players, nbullets=nb, bullets=bullets,
+                        over=over, winner=winner, init_players=init_players, init_grid=init_grid)
+    print(f"g2 {name}: resets={int(over.sum())} max_bullets={int(nb.max())}")
+
+
+# --------------------------------------------------------------------------- G3
+def gen_wrapper_trace(name, W, H, E, T, base_seed, act_seed, biased, max_steps):
+    rng = np.random.RandomState(act_seed)
+    a1 = action_stream(rng, (T, E), biased)
+    a2 = action_stream(rng, (T, E), biased)
+    envs = []
+    for i in range(E):
+        w = ew.SingleInversusRLEnv(opponent_type="selfplay", max_episode_steps=max_steps, seed=base_seed + i)
+        if (W, H) != (15, 10):
+            w.env = InversusEnv(width=W, height=H, seed=base_seed + i)
+        envs.append(w)
+    nbits = (12 * W * H + 7) // 8
+    obs0 = np.zeros((E, nbits), np.uint8)
+    extra0 = np.zeros((E, 4), np.float32)
+    for i, w in enumerate(envs):
+        g, x = ew.build_observation(w.env, PlayerId.P1)
+        obs0[i], extra0[i] = obs_bits(g), x
+    obs_step = np.zeros((T, E, nbits), np.uint8)      # obs returned by step()
+    extra_step = np.zeros((T, E, 4), np.float32)
+    obs_next = np.zeros((T, E, nbits), np.uint8)      # what the training loop carries forward
+    extra_next = np.zeros((T, E, 4), np.float32)
+    obs_p2 = np.zeros((T, E, nbits), np.uint8)        # P2-perspective obs of the PRE-step state
+    extra_p2 = np.zeros((T, E, 4), np.float32)
+    reward = np.zeros((T, E), np.float64)
+    done = np.zeros((T, E), np.uint8)
+    info_flags = np.zeros((T, E, 4), np.uint8)        # landed_hit, got_hit, win, lose
+    ep_steps = np.zeros((T, E), np.int32)
+    ep_return = np.zeros((T, E), np.float64)
+    for t in range(T):
+        for i, w in enumerate(envs):
+            seen = {}
+
+            def opp(obs, _i=i, _t=t, _seen=seen):
+                _seen["g"], _seen["x"] = obs
+                return int(a2[_t, _i])
+
+            (g, x), r, d, info = w.step(int(a1[t, i]), opponent_policy=opp)
+            obs_p2[t, i], extra_p2[t, i] = obs_bits(seen["g"]), seen["x"]
+            obs_step[t, i], extra_step[t, i] = obs_bits(g), x
+            reward[t, i], done[t, i] = r, d
+            info_flags[t, i] = (info["landed_hit"], info["got_hit"], info["win"], info["lose"])
+            ep_steps[t, i], ep_return[t, i] = info["episode_steps"], info["episode_return"]
+            if d:
+                g, x = w.reset()                 # training.py:148-151
+            obs_next[t, i], extra_next[t, i] = obs_bits(g), x
+    np.savez_compressed(os.path.join(OUT, f"g3_wrapper_{name}.npz"), W=W, H=H, base_seed=base_seed,
+                        max_steps=max_steps, a1=a1, a2=a2, obs0=obs0, extra0=extra0,
+                        obs_step=obs_step, extra_step=extra_step, obs_next=obs_next, extra_next=extra_next,
+                        obs_p2=obs_p2, extra_p2=extra_p2, reward=reward, done=done,
+                        info_flags=info_flags, ep_steps=ep_steps, ep_return=ep_return)
+    print(f"g3 {name}: dones={int(done.sum())} wins={int(info_flags[..., 2].sum())} "
+          f"losses={int(info_flags[..., 3].sum())} distinct rewards={len(np.unique(reward))}")
+
+
+# --------------------------------------------------------------------------- G4
+def gen_gae():
+    import torch
+    from inversus_rl.ppo_agent import PPOAgent
+    out = {}
+    rng = np.random.RandomState(7)
+    for name, T, N, pdone in [("128x1", 128, 1, 0.02), ("128x16", 128, 16, 0.02),
+                              ("512x4", 512, 4, 0.05), ("64x8_nodone", 64, 8, 0.0)]:
+        r = (rng.randn(T, N) * np.array([1.0, 0.01, 10.0, 0.1])[rng.randint(0, 4, (T, N))]).astype(np.float32)
+        v = rng.randn(T, N).astype(np.float32)
+        d = (rng.random_sample((T, N)) < pdone)
+        agent = PPOAgent(torch.nn.Linear(1, 1))
+        # the reference loop fills the buffer env-minor inside the time loop (training.py:128-137)
+        for t in range(T):
+            for i in range(N):
+                agent.store_step(None, None, 0, 0.0, float(v[t, i]), float(r[t, i]), bool(d[t, i]))
+        adv, ret = agent.compute_advantages()
+        out[f"{name}_r"], out[f"{name}_v"], out[f"{name}_d"] = r, v, d.astype(np.uint8)
+        out[f"{name}_adv_flat"], out[f"{name}_ret_flat"] = adv.reshape(T, N), ret.reshape(T, N)
+        # per-env: the same reference routine applied to each env's own column
+        adv_pe = np.zeros((T, N), np.float32)
+        ret_pe = np.zeros((T, N), np.float32)
+        for i in range(N):
+            agent = PPOAgent(torch.nn.Linear(1, 1))
+            for t in range(T):
+                agent.store_step(None, None, 0, 0.0, float(v[t, i]), float(r[t, i]), bool(d[t, i]))
+            a, rr = agent.compute_advantages()
+            adv_pe[:, i], ret_pe[:, i] = a, rr
+        out[f"{name}_adv_env"], out[f"{name}_ret_env"] = adv_pe, ret_pe
+        assert adv.dtype == np.float32 and ret.dtype == np.float32
+    np.savez_compressed(os.path.join(OUT, "g4_gae.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G6
+def gen_dummy(n_cases=3000):
+    """dummy_opponent_policy as a pure function of (state, draws): the global `random`
+    module's random()/shuffle() are replaced by recorded draws for the duration of a call."""
+    rng = np.random.RandomState(11)
+    env = InversusEnv(seed=5)
+    recs = {k: [] for k in ("grid", "players", "hard", "u", "perm_a", "swap_c", "perm_b", "action")}
+    real_random, real_shuffle = random.random, random.shuffle
+
+    def skewed():
+        m = rng.randint(0, 3)
+        return float(rng.uniform(0, 1) if m == 0 else rng.uniform(0, 0.3) if m == 1 else rng.uniform(0, 0.002))
+
+    try:
+        for c in range(n_cases):
+            # wander the state with random play so grids / positions / ammo vary
+            for _ in range(rng.randint(1, 6)):
+                env.step_players(ew.discrete_to_action(int(rng.randint(0, 13))),
+                                 ew.discrete_to_action(int(rng.randint(0, 13))))
+                if env.is_round_over():
+                    env.reset()
+            if rng.random_sample() < 0.15:          # force alignment cases
+                env.player2.x = env.player1.x
+            if rng.random_sample() < 0.15:
+                env.player2.y = env.player1.y
+            if rng.random_sample() < 0.05:
+                env.player2.ammo = 0
+            if rng.random_sample() < 0.03:
+                env.player2.alive = False
+            hard = int(rng.randint(0, 2))
+            u = [skewed(), skewed(), skewed()]
+            perm_a = rng.permutation(4)
+            perm_b = rng.permutation(4)
+            swap_c = int(rng.randint(0, 2))
+            draws = iter(u)
+            state = {"n4": 0}
+            a_expected = hard and (u[1] < 0.05)
+
+            def fake_random():
+                return next(draws)
+
+            def fake_shuffle(lst):
+                if len(lst) == 4:
+                    perm = perm_a if (a_expected and state["n4"] == 0) else perm_b
+                    state["n4"] += 1
+                    lst[:] = [lst[j] for j in perm]
+                elif len(lst) == 2 and swap_c:
+                    lst[0], lst[1] = lst[1], lst[0]
+
+            random.random, random.shuffle = fake_random, fake_shuffle
+            act = ew.dummy_opponent_policy(env, difficulty="hard" if hard else "easy")
+            random.random, random.shuffle = real_random, real_shuffle
+            if act.type == ActionType.NONE:
+                aid = 0
+            elif act.type == ActionType.MOVE:
+                aid = 1 + DIR_IDX[act.direction]
+            else:
+                assert act.type == ActionType.SHOOT
+                aid = 5 + DIR_IDX[act.direction]
+            recs["grid"].append(grid_words(env)); recs["players"].append(player_rows(env))
+            recs["hard"].append(hard); recs["u"].append(u); recs["perm_a"].append(perm_a)
+            recs["swap_c"].append(swap_c); recs["perm_b"].append(perm_b); recs["action"].append(aid)
+            env.player2.alive = True      # undo a forced death; real deaths were reset above
+    finally:
+        random.random, random.shuffle = real_random, real_shuffle
+    arr = {k: np.array(v) for k, v in recs.items()}
+    np.savez_compressed(os.path.join(OUT, "g6_dummy.npz"), **arr)
+    print("g6 dummy action histogram:", np.bincount(arr["action"], minlength=13))
+
+
+def main():
+    gen_spawn(15, 10)
+    gen_spawn(32, 32)
+    gen_spawn(3, 3)
+    gen_core_trace("15x10_uniform", 15, 10, 64, 512, base_seed=0, act_seed=100, biased=False)
+    gen_core_trace("15x10_biased", 15, 10, 64, 512, base_seed=1000, act_seed=101, biased=True)
+    gen_core_trace("32x32_biased", 32, 32, 16, 512, base_seed=2000, act_seed=102, biased=True)
+    gen_core_trace("7x5_biased", 7, 5, 16, 256, base_seed=3000, act_seed=103, biased=True)
+    gen_wrapper_trace("15x10_uniform", 15, 10, 32, 512, base_seed=0, act_seed=200, biased=False, max_steps=500)
+    gen_wrapper_trace("15x10_biased", 15, 10, 32, 512, base_seed=500, act_seed=201, biased=True, max_steps=500)
+    gen_wrapper_trace("15x10_timeout20", 15, 10, 16, 128, base_seed=700, act_seed=202, biased=False, max_steps=20)
+    gen_wrapper_trace("32x32_biased", 32, 32, 8, 256, base_seed=900, act_seed=203, biased=True, max_steps=100)
+    gen_gae()
+    gen_dummy()
+
+
+if __name__ == "__main__":
+    main()
