@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: env-steps/s of the batched Inversus step at 16 384 envs per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one vector step of the shard's 16 384 envs: synthetic P1 action stream (device
+Philox, the stand-in for the policy in BASELINE.json configs[1] "HIP step + obs kernels only"),
+device dummy opponent, core tick, reward/done/info, auto-reset, 12-channel observation render.
+Inputs (env state) are resident in HBM before the timed region.  Envs are sharded over ranks
+by global index with no data-path collective (weak scaling: 16 384 envs per GPU).
+
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (k_step) from HIP events on
+the launch stream; `cpu_baseline` times the CPU oracle (test infrastructure, used here only as
+the yardstick) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NUM_ENVS = 16384            # per GPU (BASELINE.json metric: "env-steps/sec at 16384 envs")
+W, H, K = 15, 10, 16
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+
+
+def algorithmic_bytes_per_env_step(w=W, h=H, k=K, selfplay=False):
+    """obs + extra + reward + done + actions + 2 x packed state."""
+    s = (w * h + 7) // 8 + 10 + 1 + 2 * k + 2 + 1 + 8
+    obs = 12 * w * h * 4 + 16
+    return (2 if selfplay else 1) * obs + 4 + 1 + 2 + 2 * s
+
+
+def cpu_baseline(difficulty, budget_s=12.0):
+    """The C oracle (bit-checked against the reference) on the host cores: same seeds, same
+    action stream, same config; bounded sample."""
+    import numpy as np
+    from oracle import oracle as orc
+    cores = min(os.cpu_count() or 1, 16)
+    n = NUM_ENVS
+    ob = orc.OracleBatch(n, W, H)
+    ob.seed_reset(np.arange(n, dtype=np.int64))
+    L = orc.lib()
+    hard = difficulty == "hard"
+    acts = [np.array([L.orc_uniform_action(1234, i, t) for i in range(n)], np.uint8) for t in range(4)]
+    ob.step(acts[0], None, hard=hard, opp_seed=1, nthreads=cores)          # warm-up
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        ob.step(acts[steps % 4], None, hard=hard, opp_seed=1, nthreads=cores)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or steps >= 4000:
+            break
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} vector steps x {n} envs, vs_dummy_{difficulty}, C oracle (OpenMP over envs), obs rendered"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--difficulty", default="easy", choices=["easy", "hard"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    import numpy as np
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = NUM_ENVS
+    off = rank * n                                   # contiguous global env range per rank
+    b = DeviceEnvBatch(n, W, H, K, opponent="dummy", difficulty=args.difficulty, opp_seed=1, env_offset=off)
+    b.seed(off + np.arange(n, dtype=np.int64))       # seed = base 0 + global env index
+    b.reset()
+    out = b._alloc_out((), True, False, False, None)  # fixed output buffers: no allocator in the loop
+    a1 = b.uniform_actions(1234, 0)
+
+    def one_step(t):
+        b.uniform_actions(1234, t, out=a1)
+        b.step(a1, None, auto_reset=True, out=out)
+
+    for t in range(args.warmup):
+        one_step(t)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        t = args.warmup + k
+        b.uniform_actions(1234, t, out=a1)
+        ev[k][0].record()                            # HIP events on the launch stream, around k_step only
+        b.step(a1, None, auto_reset=True, out=out)
+        ev[k][1].record()
+    fence()
+    dt = time.perf_counter() - t0
+    b.check()
+
+    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / args.steps
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        bytes_per_launch = algorithmic_bytes_per_env_step() * n
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        res = {
+            "metric": "env-steps/sec at 16384 envs per MI355X",
+            "value": world * n * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"vs_dummy_{args.difficulty}: {n} envs/GPU, 15x10 grid, K=16, step+obs kernels only "
+                                   "(Philox a1 stream, device dummy a2, reward/done, auto-reset, 12-ch obs)",
+                       "envs_per_gpu": n, "sharding": f"env-shards x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_step", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step()},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.difficulty)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

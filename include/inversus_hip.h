@@ -1,0 +1,177 @@
+/*
+ * inversus_hip.h -- C ABI of libinversus_hip.so: the MI355X (gfx950) batched
+ * Inversus environment, observation render, reward/termination and GAE scan.
+ *
+ * The reference (pure Python) has no FFI; its boundary for this path is the
+ * duck-typed API of inversus_rl/env_wrappers.py (MultiEnvRunner :447-528,
+ * SingleInversusRLEnv :248-444, build_observation :173-245, discrete_to_action
+ * :20-66) over inversus/core.py (InversusEnv :17-544), plus
+ * PPOAgent.compute_advantages (inversus_rl/ppo_agent.py:127-157).  Every entry
+ * point below names the reference interface it replaces; INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (`stream` is a
+ *     hipStream_t passed as void*; NULL = the default stream).
+ *   - every data pointer is a DEVICE pointer unless the parameter says `_host`.
+ *   - all launches are asynchronous on `stream`; nothing synchronises except
+ *     inv_check() and the `_host` copies.
+ *   - return value: INV_OK or a negative inv_status; inv_last_error() gives text.
+ *   - env i of a handle has GLOBAL index env_offset + i (multi-GPU sharding: one
+ *     handle per rank over a contiguous global range; results do not depend on
+ *     how the range is cut).
+ *
+ * Canonical encodings (also used by oracle/ and tests/golden/)
+ *   grid    u32 words [N][GW], GW = ceil(W*H/32); bit (y*W + x) set <=> WHITE
+ *   player  i32 [N][2][5] = x, y, ammo, reload_counter, alive (P1 then P2)
+ *   bullet  u16 [N][K] = x | y<<6 | dir<<12 | owner<<14 ; list order is state
+ *           dir 0=UP 1=RIGHT 2=DOWN 3=LEFT (obs channel order), owner 0=P1 1=P2
+ *   obs     f32 [N][12][H][W], extra f32 [N][4]  (env_wrappers.py:185-245)
+ *   action  u8 0..12 (env_wrappers.py:24-37): type=(id+3)>>2, dir=(id-1)&3
+ */
+#ifndef INVERSUS_HIP_H
+#define INVERSUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INV_ABI_VERSION 1
+
+typedef enum {
+    INV_OK = 0,
+    INV_ERR_BAD_ARG = -1,
+    INV_ERR_BAD_DIMS = -2,        /* W or H < 3: "empty range for randrange" (core.py:69-70) */
+    INV_ERR_HIP = -3,
+    INV_ERR_BAD_ACTION = -4,      /* action id outside 0..12: ValueError (env_wrappers.py:66) */
+    INV_ERR_BULLET_OVERFLOW = -5, /* more than max_bullets live bullets in one env */
+    INV_ERR_NO_OPPONENT = -6      /* a2 == NULL on a handle without a device opponent (env_wrappers.py:309) */
+} inv_status;
+
+enum { INV_OPP_EXTERNAL = 0,      /* "selfplay": caller supplies a2 every step */
+       INV_OPP_DUMMY = 1 };       /* scripted dummy computed on the device (env_wrappers.py:69-170) */
+enum { INV_EASY = 0, INV_HARD = 1 };
+
+/* inv_step flags */
+enum {
+    INV_PHASE_ACTIONS = 1u,       /* core.py:510-525 */
+    INV_PHASE_RELOAD  = 2u,       /* core.py:528 */
+    INV_PHASE_BULLETS = 4u,       /* core.py:531 */
+    INV_PHASE_WRAPPER = 8u,       /* step_count, reward, done, info (env_wrappers.py:318-442) */
+    INV_STEP_AUTO_RESET = 16u,    /* training.py:148-151: reset done envs, emit the reset obs */
+    INV_STEP_DEFAULT  = 15u
+};
+
+/* info_flags bits (env_wrappers.py:360-369, 413-427) */
+enum { INV_INFO_LANDED_HIT = 1, INV_INFO_GOT_HIT = 2, INV_INFO_WIN = 4, INV_INFO_LOSE = 8 };
+
+enum { INV_GAE_REFERENCE_FLAT = 0,  /* one chain over the env-interleaved buffer (training.py:128-137 fill order) */
+       INV_GAE_PER_ENV = 1 };       /* independent chain per env column of a [T][N] buffer */
+
+typedef struct inv_handle inv_handle;
+
+typedef struct {
+    int32_t  num_envs;            /* envs in this handle (shard) */
+    int32_t  width, height;       /* 3..64; reference default 15 x 10 (config.py:7-8) */
+    int32_t  max_bullets;         /* K, 1..64; 16 covers every reachable state up to 64x64 */
+    int32_t  max_episode_steps;   /* env_wrappers.py:251, default 500 */
+    int32_t  opponent;            /* INV_OPP_* */
+    int32_t  difficulty;          /* INV_EASY / INV_HARD */
+    int32_t  device;              /* HIP device ordinal */
+    uint32_t opp_seed;            /* key of the dummy's counter RNG */
+    int64_t  env_offset;          /* global index of env 0 */
+} inv_config;
+
+/* Optional per-step outputs; any pointer may be NULL. */
+typedef struct {
+    float   *obs, *extra;         /* P1 observation of the state the caller continues from */
+    float   *obs_p2, *extra_p2;   /* same state from P2's perspective (self-play opponent input) */
+    float   *reward;              /* f32(f64 reward), env_wrappers.py:525 */
+    double  *reward64;            /* the f64 sum itself (parity checks) */
+    uint8_t *done;
+    uint8_t *info_flags;          /* INV_INFO_* */
+    int32_t *episode_steps;       /* info["episode_steps"] */
+    double  *episode_return;      /* info["episode_return"] */
+} inv_step_out;
+
+/* Canonical state view for inv_get_state / inv_set_state; NULL members are skipped. */
+typedef struct {
+    uint32_t *grid;               /* [N][GW] */
+    int32_t  *players;            /* [N][2][5] */
+    int32_t  *nbullets;           /* [N] */
+    uint16_t *bullets;            /* [N][K] (entries >= nbullets read back as 0) */
+    int32_t  *step_count;         /* [N] */
+    double   *episode_return;     /* [N] */
+    uint8_t  *prev_alive;         /* [N][2] */
+    uint32_t *opp_ctr;            /* [N] */
+    uint32_t *mt;                 /* [N][624] MT19937 words */
+    int32_t  *mt_index;           /* [N] 0..624 */
+} inv_state_view;
+
+const char *inv_last_error(void);
+int  inv_abi_version(void);
+
+/* MultiEnvRunner.__init__ (env_wrappers.py:450-469) minus the seeding/reset. */
+int  inv_create(const inv_config *cfg, inv_handle **out);
+int  inv_destroy(inv_handle *h);
+int  inv_get_config(const inv_handle *h, inv_config *cfg);
+/* bytes of one env's obs / words per grid, for sizing caller buffers */
+int64_t inv_obs_floats_per_env(const inv_handle *h);   /* 12*H*W */
+int32_t inv_grid_words(const inv_handle *h);           /* GW */
+
+/* random.Random(seed) per env (core.py:41,58): CPython's init_by_array on the 32-bit
+ * words of abs(seed).  seeds_host: N int64 in HOST memory.  Also zeroes opp_ctr. */
+int  inv_seed(inv_handle *h, const int64_t *seeds_host, void *stream);
+/* Same, only for envs whose mask_host byte is non-zero (SingleInversusRLEnv.reset(seed=...) on one env). */
+int  inv_seed_masked(inv_handle *h, const int64_t *seeds_host, const uint8_t *mask_host, void *stream);
+
+/* SingleInversusRLEnv.reset() (env_wrappers.py:272-284) -> InversusEnv.reset()
+ * (core.py:55-154) on every env whose mask byte is non-zero (mask NULL = all):
+ * continues each env's own MT stream. */
+int  inv_reset(inv_handle *h, const uint8_t *mask, void *stream);
+
+/* MultiEnvRunner.step (env_wrappers.py:485-528) = per env discrete_to_action +
+ * InversusEnv.step_players (core.py:497-531) + reward/done/info (:318-442) +
+ * build_observation (:173-245); with INV_STEP_AUTO_RESET also the training loop's
+ * reset-and-patch (training.py:148-151).  a2 NULL -> device dummy opponent. */
+int  inv_step(inv_handle *h, const uint8_t *a1, const uint8_t *a2, uint32_t flags,
+              const inv_step_out *out, void *stream);
+/* Same, stepping only envs whose (device) mask byte is non-zero; the others keep their state
+ * and their output slots are not written (SingleInversusRLEnv.step on runner.envs[i]). */
+int  inv_step_masked(inv_handle *h, const uint8_t *mask, const uint8_t *a1, const uint8_t *a2, uint32_t flags,
+                     const inv_step_out *out, void *stream);
+
+/* build_observation(env, player) (env_wrappers.py:173-245); player 0 = P1, 1 = P2. */
+int  inv_render_obs(inv_handle *h, int32_t player, float *obs, float *extra, void *stream);
+
+/* State poke / dump, the SoA form of the reference tests' direct field access
+ * (tests/test_bullet_collision.py etc. set env.bullets / env.player1.x / _set_tile). */
+int  inv_get_state(inv_handle *h, const inv_state_view *dst, void *stream);
+int  inv_set_state(inv_handle *h, const inv_state_view *src, void *stream);
+
+/* Synchronise `stream` and return (then clear) the sticky device error:
+ * INV_OK, INV_ERR_BAD_ACTION or INV_ERR_BULLET_OVERFLOW. */
+int  inv_check(inv_handle *h, void *stream);
+
+/* PPOAgent.compute_advantages (ppo_agent.py:127-157), strict f32, no FMA.
+ * r, v, adv, ret: f32 [T][N]; done u8 [T][N]; gamma_lam = f32(f64 gamma*lam).
+ * last_value: f32[N] (per_env; NULL = 0) or f32[1] (flat; NULL = 0). */
+int  inv_gae(const float *r, const float *v, const uint8_t *done, int32_t T, int32_t N,
+             float gamma, float gamma_lam, const float *last_value, int32_t layout,
+             float *adv, float *ret, void *stream);
+
+/* Synthetic action stream (bench stand-in for a policy): a[i] = Philox(seed; t, env_offset+i) mod 13. */
+int  inv_uniform_actions(uint8_t *a, int32_t n, uint32_t seed, int64_t env_offset, uint32_t t, void *stream);
+
+/* T vector steps in ONE launch with pre-supplied actions a1[T][N] (a2[T][N] or NULL),
+ * writing the rollout buffers obs[T][N][12][H][W] ... -- the persistent multi-step form
+ * of inv_step (always auto-resets).  Outputs as inv_step_out with a leading T dim. */
+int  inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2,
+                 const inv_step_out *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,498 @@
+// inv_api.hip -- kernels and the C ABI (include/inversus_hip.h) of libinversus_hip.so.
+//
+// gfx950 only.  One wavefront per env (see inv_device.h); 4 envs per 256-thread block, no
+// workgroup barriers.  Every entry point is asynchronous on the caller's stream.
+#include "inv_device.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+using namespace inv;
+
+// =================================================================== kernels
+
+// MultiEnvRunner.step for every env of the shard, T times (T = 1: inv_step; T > 1: inv_rollout).
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int env = blockIdx.x * kWavesPerBlock + wv;
+    if (env >= a.d.N) return;                       // wave-uniform; no block barriers below
+    if (a.mask && rfl((int)a.mask[env]) == 0) return;
+    const Dims &d = a.d;
+    uint32_t *g = lds + wv * d.scr_words;           // [GW]   tile grid bitstring
+    uint32_t *slots = g + d.GW;                     // [K]    bullet compaction slots
+    uint32_t *scr = slots + d.K;                    // [>=624] obs bitstring / MT twist scratch
+
+    Env e;
+    load_env(d, a.s, env, lane, g, e);
+    uint32_t err = 0u;
+    const size_t obs_stride = (size_t)12 * d.WH;
+
+    for (int t = 0; t < a.T; ++t) {
+        const size_t idx = (size_t)t * d.N + env;
+        const int act1 = rfl((int)a.a1[idx]);
+        int act2;
+        if (a.a2) {
+            act2 = rfl((int)a.a2[idx]);
+        } else {
+            act2 = rfl(dummy_action(d, g, e, a.hard, a.opp_seed, a.env_offset + (uint32_t)env, e.opp_ctr));
+            e.opp_ctr += 1u;
+        }
+        double reward = 0.0;
+        int done = 0;
+        uint32_t info = 0u;
+        const bool bad = act1 > 12 || act2 > 12;    // ValueError in the reference (env_wrappers.py:66): env left untouched
+        if (bad) err |= ERR_BAD_ACTION;
+
+        if (!bad) {
+            if (a.flags & INV_PHASE_ACTIONS) {      // core.py:510-525: P1 then P2
+                apply_action(d, g, lane, 0, act1, e, err);
+                apply_action(d, g, lane, 1, act2, e, err);
+            }
+            if (a.flags & INV_PHASE_RELOAD) { reload(e.p[0]); reload(e.p[1]); }            // :528
+            int tile_diff = 0;
+            if (a.flags & INV_PHASE_BULLETS) tile_diff = update_bullets(d, g, slots, lane, e);   // :531
+
+            if (a.flags & INV_PHASE_WRAPPER) {      // env_wrappers.py:333-442, f64 adds in the reference's order
+                e.step_count += 1;
+                const Player &p1 = e.p[0], &p2 = e.p[1];
+                if (tile_diff > 0) reward += (double)tile_diff * 0.01;
+                if (e.prev2 && !p2.alive) { reward += 1.0; info |= INV_INFO_LANDED_HIT; }
+                if (e.prev1 && !p1.alive) { reward -= 0.01; info |= INV_INFO_GOT_HIT; }
+                if (p1.alive && p1.ammo == 0) reward -= 0.001;
+                if (p1.alive && p2.alive) {
+                    const int dist = abs(p1.x - p2.x) + abs(p1.y - p2.y);
+                    reward += a.s.prox[dist];
+                    const bool aligned = p1.x == p2.x || p1.y == p2.y;
+                    if (aligned) reward += 0.002;
+                    if (act1 >= 5 && aligned && p1.ammo > 0) {
+                        const int shot = (act1 - 1) & 3;
+                        bool aiming = false;
+                        if (p1.x == p2.x) aiming = (p1.y < p2.y && shot == 2) || (p1.y > p2.y && shot == 0);
+                        else aiming = (p1.x < p2.x && shot == 1) || (p1.x > p2.x && shot == 3);
+                        if (aiming) reward += 0.05;
+                    }
+                }
+                const bool over = !(p1.alive && p2.alive);
+                if (over) {
+                    done = 1;
+                    if (p1.alive && !p2.alive) { reward += 10.0; info |= INV_INFO_WIN; }
+                    else if (p2.alive && !p1.alive) { reward -= 0.1; info |= INV_INFO_LOSE; }
+                } else {
+                    reward -= 0.001;
+                }
+                e.prev1 = p1.alive;
+                e.prev2 = p2.alive;
+                if (e.step_count >= d.max_steps) {
+                    done = 1;
+                    if (!over) reward -= 2.0;
+                }
+                e.ep_ret += reward;
+            }
+        }
+
+        if (lane == 0) {
+            if (a.o.reward) a.o.reward[idx] = (float)reward;
+            if (a.o.reward64) a.o.reward64[idx] = reward;
+            if (a.o.done) a.o.done[idx] = (uint8_t)done;
+            if (a.o.info_flags) a.o.info_flags[idx] = (uint8_t)info;
+            if (a.o.episode_steps) a.o.episode_steps[idx] = e.step_count;
+            if (a.o.episode_return) a.o.episode_return[idx] = e.ep_ret;
+        }
+
+        if (done && (a.flags & INV_STEP_AUTO_RESET)) reset_env(d, a.s, env, lane, g, scr, e);   // training.py:148-151
+
+        if (a.o.obs) render_obs(d, g, scr, lane, 0, e, a.o.obs + idx * obs_stride, a.o.extra ? a.o.extra + idx * 4 : nullptr);
+        if (a.o.obs_p2) render_obs(d, g, scr, lane, 1, e, a.o.obs_p2 + idx * obs_stride, a.o.extra_p2 ? a.o.extra_p2 + idx * 4 : nullptr);
+    }
+
+    store_env(d, a.s, env, lane, g, e);
+    if (err && lane == 0) atomicOr(a.s.err, err);
+}
+
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_reset(Dims d, State s, const uint8_t *mask)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int env = blockIdx.x * kWavesPerBlock + wv;
+    if (env >= d.N) return;
+    if (mask && rfl((int)mask[env]) == 0) return;
+    uint32_t *g = lds + wv * d.scr_words;
+    uint32_t *scr = g + d.GW + d.K;
+    Env e;
+    load_env(d, s, env, lane, g, e);
+    reset_env(d, s, env, lane, g, scr, e);
+    store_env(d, s, env, lane, g, e);
+}
+
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims d, State s, int player, float *obs, float *extra)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int env = blockIdx.x * kWavesPerBlock + wv;
+    if (env >= d.N) return;
+    uint32_t *g = lds + wv * d.scr_words;
+    uint32_t *scr = g + d.GW + d.K;
+    Env e;
+    load_env(d, s, env, lane, g, e);
+    render_obs(d, g, scr, lane, player, e, obs + (size_t)env * 12 * d.WH, extra ? extra + (size_t)env * 4 : nullptr);
+}
+
+// random.Random(seed): init_by_array(key) of CPython's _randommodule.c, one thread per env.
+// key[env] = {low word, high word of abs(seed)}; key length 2 iff the high word is non-zero.
+__global__ void k_seed(int N, uint32_t *mt, uint32_t *head, const uint32_t *key, const uint8_t *mask)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    if (mask && !mask[env]) return;
+    uint32_t *m = mt + (size_t)env * kMtStride;
+    const uint32_t k0 = key[2 * env], k1 = key[2 * env + 1];
+    const int klen = k1 ? 2 : 1;
+    uint32_t prev = 19650218u;                       // init_genrand(19650218)
+    m[0] = prev;
+    for (int i = 1; i < 624; ++i) {
+        prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i;
+        m[i] = prev;
+    }
+    int i = 1, j = 0;
+    prev = m[0];
+    for (int k = 624; k; --k) {
+        const uint32_t cur = (m[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? k1 : k0) + (uint32_t)j;
+        m[i] = cur;
+        prev = cur;
+        ++i; ++j;
+        if (i >= 624) { m[0] = prev; i = 1; }
+        if (j >= klen) j = 0;
+    }
+    for (int k = 623; k; --k) {
+        const uint32_t cur = (m[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+        m[i] = cur;
+        prev = cur;
+        ++i;
+        if (i >= 624) { m[0] = prev; i = 1; }
+    }
+    m[0] = 0x80000000u;
+    head[(size_t)env * kHeadWords + HD_MTI] = 624u;
+    head[(size_t)env * kHeadWords + HD_OPP] = 0u;
+}
+
+__global__ void k_get_state(Dims d, State s, inv_state_view v)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.N) return;
+    const uint32_t *h = s.head + (size_t)env * kHeadWords;
+    const uint32_t fl = h[HD_FLAGS];
+    const int nb = (int)((fl >> 8) & 255u);
+    if (v.players) {
+        int32_t *p = v.players + (size_t)env * 10;
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t w = h[q];
+            p[5 * q + 0] = (int)(w & 255u); p[5 * q + 1] = (int)((w >> 8) & 255u);
+            p[5 * q + 2] = (int)((w >> 16) & 255u); p[5 * q + 3] = (int)(w >> 24);
+            p[5 * q + 4] = (int)((fl >> q) & 1u);
+        }
+    }
+    if (v.nbullets) v.nbullets[env] = nb;
+    if (v.bullets) for (int i = 0; i < d.K; ++i) v.bullets[(size_t)env * d.K + i] = i < nb ? s.bullets[(size_t)env * d.K + i] : (uint16_t)0;
+    if (v.grid) for (int w = 0; w < d.GW; ++w) v.grid[(size_t)env * d.GW + w] = s.grid[(size_t)env * d.GW + w];
+    if (v.step_count) v.step_count[env] = (int32_t)h[HD_STEP];
+    if (v.episode_return) v.episode_return[env] = __longlong_as_double((long long)((uint64_t)h[HD_RET_LO] | ((uint64_t)h[HD_RET_HI] << 32)));
+    if (v.prev_alive) { v.prev_alive[2 * env] = (uint8_t)((fl >> 2) & 1u); v.prev_alive[2 * env + 1] = (uint8_t)((fl >> 3) & 1u); }
+    if (v.opp_ctr) v.opp_ctr[env] = h[HD_OPP];
+    if (v.mt_index) v.mt_index[env] = (int32_t)h[HD_MTI];
+    if (v.mt) for (int i = 0; i < 624; ++i) v.mt[(size_t)env * 624 + i] = s.mt[(size_t)env * kMtStride + i];
+}
+
+__global__ void k_set_state(Dims d, State s, inv_state_view v)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= d.N) return;
+    uint32_t *h = s.head + (size_t)env * kHeadWords;
+    uint32_t fl = h[HD_FLAGS];
+    if (v.players) {
+        const int32_t *p = v.players + (size_t)env * 10;
+        for (int q = 0; q < 2; ++q) {
+            h[q] = ((uint32_t)p[5 * q + 0] & 255u) | (((uint32_t)p[5 * q + 1] & 255u) << 8) |
+                   (((uint32_t)p[5 * q + 2] & 255u) << 16) | (((uint32_t)p[5 * q + 3] & 255u) << 24);
+            fl = (fl & ~(1u << q)) | ((p[5 * q + 4] ? 1u : 0u) << q);
+        }
+    }
+    if (v.nbullets) {
+        int nb = v.nbullets[env];
+        if (nb > d.K) { nb = d.K; atomicOr(s.err, ERR_BULLET_OVERFLOW); }
+        if (nb < 0) nb = 0;
+        fl = (fl & ~0xff00u) | ((uint32_t)nb << 8);
+    }
+    if (v.prev_alive) fl = (fl & ~(FL_PREV1 | FL_PREV2)) | (v.prev_alive[2 * env] ? FL_PREV1 : 0u) | (v.prev_alive[2 * env + 1] ? FL_PREV2 : 0u);
+    h[HD_FLAGS] = fl;
+    if (v.bullets) for (int i = 0; i < d.K; ++i) s.bullets[(size_t)env * d.K + i] = v.bullets[(size_t)env * d.K + i];
+    if (v.grid) {
+        const uint32_t lastmask = (d.WH & 31) ? ((1u << (d.WH & 31)) - 1u) : 0xffffffffu;
+        for (int w = 0; w < d.GW; ++w) s.grid[(size_t)env * d.GW + w] = v.grid[(size_t)env * d.GW + w] & (w == d.GW - 1 ? lastmask : 0xffffffffu);
+    }
+    if (v.step_count) h[HD_STEP] = (uint32_t)v.step_count[env];
+    if (v.episode_return) {
+        const uint64_t rb = (uint64_t)__double_as_longlong(v.episode_return[env]);
+        h[HD_RET_LO] = (uint32_t)rb; h[HD_RET_HI] = (uint32_t)(rb >> 32);
+    }
+    if (v.opp_ctr) h[HD_OPP] = v.opp_ctr[env];
+    if (v.mt_index) h[HD_MTI] = (uint32_t)v.mt_index[env];
+    if (v.mt) for (int i = 0; i < 624; ++i) s.mt[(size_t)env * kMtStride + i] = v.mt[(size_t)env * 624 + i];
+}
+
+__global__ void k_init_head(int N, uint32_t *head)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    uint32_t *h = head + (size_t)env * kHeadWords;
+    // a blank env: players at (1,1), 6 ammo, alive; MT unseeded (index 624 over a zero state)
+    h[HD_P1] = 1u | (1u << 8) | (6u << 16);
+    h[HD_P2] = 1u | (1u << 8) | (6u << 16);
+    h[HD_FLAGS] = FL_ALIVE1 | FL_ALIVE2 | FL_PREV1 | FL_PREV2;
+    h[HD_STEP] = 0u; h[HD_OPP] = 0u; h[HD_MTI] = 624u; h[HD_RET_LO] = 0u; h[HD_RET_HI] = 0u;
+}
+
+__global__ void k_uniform_actions(uint8_t *a, int n, uint32_t seed, uint32_t env_offset, uint32_t t)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const U4 x = philox4x32(t, env_offset + (uint32_t)i, 0u, kTagAction, seed, kKey1);
+    a[i] = (uint8_t)__umulhi(x.x, 13u);
+}
+
+// =================================================================== host side
+
+struct inv_handle {
+    inv_config cfg;
+    Dims d;
+    State s;
+    double *prox;
+    uint32_t *keys;      // [N][2] staging for inv_seed, followed by N mask bytes
+    uint32_t *keys_host; // pinned, same layout
+    int lds_bytes;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(INV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+static inline int env_blocks(int n) { return (n + kWavesPerBlock - 1) / kWavesPerBlock; }
+
+extern "C" {
+
+const char *inv_last_error(void) { return g_err; }
+int inv_abi_version(void) { return INV_ABI_VERSION; }
+
+int inv_create(const inv_config *cfg, inv_handle **out)
+{
+    if (!cfg || !out) return fail(INV_ERR_BAD_ARG, "inv_create: NULL argument");
+    *out = nullptr;
+    if (cfg->num_envs <= 0) return fail(INV_ERR_BAD_ARG, "inv_create: num_envs must be > 0");
+    if (cfg->width < 3 || cfg->height < 3)
+        return fail(INV_ERR_BAD_DIMS, "empty range for randrange() (%d, %d, %d)", 1, cfg->width < 3 ? cfg->width - 1 : cfg->height - 1, 0);
+    if (cfg->width > 64 || cfg->height > 64) return fail(INV_ERR_BAD_DIMS, "inv_create: width/height must be <= 64");
+    if (cfg->max_bullets < 1 || cfg->max_bullets > 64) return fail(INV_ERR_BAD_ARG, "inv_create: max_bullets must be 1..64");
+    if (cfg->max_episode_steps < 1) return fail(INV_ERR_BAD_ARG, "inv_create: max_episode_steps must be >= 1");
+    if (cfg->opponent != INV_OPP_EXTERNAL && cfg->opponent != INV_OPP_DUMMY) return fail(INV_ERR_BAD_ARG, "Unknown opponent_type: %d", cfg->opponent);
+
+    HIP_TRY(hipSetDevice(cfg->device));
+    inv_handle *h = new (std::nothrow) inv_handle();
+    if (!h) return fail(INV_ERR_BAD_ARG, "inv_create: out of host memory");
+    h->cfg = *cfg;
+    Dims &d = h->d;
+    d.N = cfg->num_envs; d.W = cfg->width; d.H = cfg->height; d.WH = d.W * d.H; d.K = cfg->max_bullets;
+    d.GW = (d.WH + 31) / 32;
+    d.OW = (12 * d.WH + 31) / 32;
+    d.F4 = 3 * d.WH;
+    const int scratch = d.OW > 624 ? d.OW : 624;
+    d.scr_words = (d.GW + d.K + scratch + 3) & ~3;
+    d.max_steps = cfg->max_episode_steps;
+    h->lds_bytes = d.scr_words * 4 * kWavesPerBlock;
+
+    const size_t n = (size_t)d.N;
+    HIP_TRY(hipMalloc(&h->s.head, n * kHeadWords * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->s.grid, n * d.GW * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->s.bullets, n * d.K * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc(&h->s.mt, n * kMtStride * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->s.err, sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&h->prox, (size_t)(d.W + d.H + 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->keys, n * 2 * sizeof(uint32_t) + n));
+    HIP_TRY(hipHostMalloc(&h->keys_host, n * 2 * sizeof(uint32_t) + n));
+    HIP_TRY(hipMemset(h->s.grid, 0, n * d.GW * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->s.bullets, 0, n * d.K * sizeof(uint16_t)));
+    HIP_TRY(hipMemset(h->s.mt, 0, n * kMtStride * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->s.err, 0, sizeof(uint32_t)));
+
+    // env_wrappers.py:378-382: 0.002 * (1.0 - dist / max_dist), IEEE f64 on the host
+    const int max_dist = d.W + d.H;
+    double prox[129];
+    for (int dist = 0; dist <= max_dist; ++dist) prox[dist] = 0.002 * (1.0 - (double)dist / (double)max_dist);
+    HIP_TRY(hipMemcpy(h->prox, prox, (size_t)(max_dist + 1) * sizeof(double), hipMemcpyHostToDevice));
+    h->s.prox = h->prox;
+
+    hipLaunchKernelGGL(k_init_head, dim3((d.N + 255) / 256), dim3(256), 0, 0, d.N, h->s.head);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    *out = h;
+    return INV_OK;
+}
+
+int inv_destroy(inv_handle *h)
+{
+    if (!h) return INV_OK;
+    void *dev[] = { h->s.head, h->s.grid, h->s.bullets, h->s.mt, h->s.err, h->prox, h->keys };
+    for (void *p : dev) (void)hipFree(p);
+    (void)hipHostFree(h->keys_host);
+    delete h;
+    return INV_OK;
+}
+
+int inv_get_config(const inv_handle *h, inv_config *cfg)
+{
+    if (!h || !cfg) return fail(INV_ERR_BAD_ARG, "inv_get_config: NULL argument");
+    *cfg = h->cfg;
+    return INV_OK;
+}
+
+int64_t inv_obs_floats_per_env(const inv_handle *h) { return h ? (int64_t)12 * h->d.WH : 0; }
+int32_t inv_grid_words(const inv_handle *h) { return h ? h->d.GW : 0; }
+
+int inv_seed_masked(inv_handle *h, const int64_t *seeds_host, const uint8_t *mask_host, void *stream)
+{
+    if (!h || !seeds_host) return fail(INV_ERR_BAD_ARG, "inv_seed: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->d.N;
+    HIP_TRY(hipStreamSynchronize(st));              // keys_host may still feed an earlier copy
+    uint8_t *mh = reinterpret_cast<uint8_t *>(h->keys_host + 2 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t sd = seeds_host[i];
+        const uint64_t a = sd < 0 ? (uint64_t)0 - (uint64_t)sd : (uint64_t)sd;   // abs(seed), random_seed()
+        h->keys_host[2 * i] = (uint32_t)(a & 0xffffffffu);
+        h->keys_host[2 * i + 1] = (uint32_t)(a >> 32);
+        mh[i] = mask_host ? mask_host[i] : (uint8_t)1;
+    }
+    HIP_TRY(hipMemcpyAsync(h->keys, h->keys_host, n * 2 * sizeof(uint32_t) + n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_seed, dim3((h->d.N + 63) / 64), dim3(64), 0, st, h->d.N, h->s.mt, h->s.head, h->keys,
+                       reinterpret_cast<const uint8_t *>(h->keys + 2 * n));
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+int inv_seed(inv_handle *h, const int64_t *seeds_host, void *stream) { return inv_seed_masked(h, seeds_host, nullptr, stream); }
+
+int inv_reset(inv_handle *h, const uint8_t *mask, void *stream)
+{
+    if (!h) return fail(INV_ERR_BAD_ARG, "inv_reset: NULL handle");
+    hipLaunchKernelGGL(k_reset, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes, (hipStream_t)stream,
+                       h->d, h->s, mask);
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+static int launch_step(inv_handle *h, int T, const uint8_t *mask, const uint8_t *a1, const uint8_t *a2, uint32_t flags, const inv_step_out *out, void *stream)
+{
+    if (!h || !a1) return fail(INV_ERR_BAD_ARG, "inv_step: NULL handle or a1");
+    if (!a2 && h->cfg.opponent != INV_OPP_DUMMY)
+        return fail(INV_ERR_NO_OPPONENT, "opponent_policy required for selfplay mode");
+    StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.d = h->d; a.s = h->s; a.mask = mask; a.a1 = a1; a.a2 = a2;
+    if (out) a.o = *out;
+    if ((a.o.extra && !a.o.obs) || (a.o.extra_p2 && !a.o.obs_p2)) return fail(INV_ERR_BAD_ARG, "inv_step: extra without obs");
+    a.flags = flags;
+    a.opponent = h->cfg.opponent;
+    a.hard = h->cfg.difficulty == INV_HARD;
+    a.opp_seed = h->cfg.opp_seed;
+    a.env_offset = (uint32_t)h->cfg.env_offset;
+    a.T = T;
+    hipLaunchKernelGGL(k_step, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+int inv_step(inv_handle *h, const uint8_t *a1, const uint8_t *a2, uint32_t flags, const inv_step_out *out, void *stream)
+{
+    return launch_step(h, 1, nullptr, a1, a2, flags, out, stream);
+}
+
+int inv_step_masked(inv_handle *h, const uint8_t *mask, const uint8_t *a1, const uint8_t *a2, uint32_t flags,
+                    const inv_step_out *out, void *stream)
+{
+    return launch_step(h, 1, mask, a1, a2, flags, out, stream);
+}
+
+int inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2, const inv_step_out *out, void *stream)
+{
+    if (T < 1) return fail(INV_ERR_BAD_ARG, "inv_rollout: T must be >= 1");
+    return launch_step(h, T, nullptr, a1, a2, INV_STEP_DEFAULT | INV_STEP_AUTO_RESET, out, stream);
+}
+
+int inv_render_obs(inv_handle *h, int32_t player, float *obs, float *extra, void *stream)
+{
+    if (!h || !obs) return fail(INV_ERR_BAD_ARG, "inv_render_obs: NULL argument");
+    if (player != 0 && player != 1) return fail(INV_ERR_BAD_ARG, "Invalid player ID: %d", player);   // core.py:198
+    hipLaunchKernelGGL(k_render, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes, (hipStream_t)stream,
+                       h->d, h->s, player, obs, extra);
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+int inv_get_state(inv_handle *h, const inv_state_view *dst, void *stream)
+{
+    if (!h || !dst) return fail(INV_ERR_BAD_ARG, "inv_get_state: NULL argument");
+    hipLaunchKernelGGL(k_get_state, dim3((h->d.N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->d, h->s, *dst);
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+int inv_set_state(inv_handle *h, const inv_state_view *src, void *stream)
+{
+    if (!h || !src) return fail(INV_ERR_BAD_ARG, "inv_set_state: NULL argument");
+    hipLaunchKernelGGL(k_set_state, dim3((h->d.N + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->d, h->s, *src);
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+int inv_check(inv_handle *h, void *stream)
+{
+    if (!h) return fail(INV_ERR_BAD_ARG, "inv_check: NULL handle");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t e = 0u;
+    HIP_TRY(hipMemcpyAsync(&e, h->s.err, sizeof e, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (e) {
+        HIP_TRY(hipMemsetAsync(h->s.err, 0, sizeof e, st));
+        if (e & ERR_BAD_ACTION) return fail(INV_ERR_BAD_ACTION, "Invalid action_id, must be 0-12");
+        return fail(INV_ERR_BULLET_OVERFLOW, "more than max_bullets=%d live bullets in one env", h->d.K);
+    }
+    return INV_OK;
+}
+
+int inv_uniform_actions(uint8_t *a, int32_t n, uint32_t seed, int64_t env_offset, uint32_t t, void *stream)
+{
+    if (!a || n < 0) return fail(INV_ERR_BAD_ARG, "inv_uniform_actions: bad argument");
+    if (n == 0) return INV_OK;
+    hipLaunchKernelGGL(k_uniform_actions, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, n, seed, (uint32_t)env_offset, t);
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,499 @@
+// inv_device.h -- device-side building blocks of the gfx950 Inversus env kernels.
+//
+// Execution model: ONE WAVEFRONT (64 lanes) PER ENV.  Per-env scalars (players, ammo,
+// counters, reward) are wave-uniform and live in SGPRs via readfirstlane; lane i < K owns
+// bullet slot i; the tile grid (1 bit per tile, row-major bitstring) and the packed
+// observation bitstring are staged in the wave's private LDS slice.  No workgroup
+// barriers anywhere: waves of a block never communicate, only lanes of one wave do.
+//
+// Reference semantics restated here (file:line relative to the reference checkout):
+//   inversus/core.py:55-154 (reset), :249-381 (move / shoot / wide shot), :383-397
+//   (reload), :399-475 (bullet advance, cancel, merge, flip, kill), :497-531 (tick order);
+//   inversus_rl/env_wrappers.py:20-66 (action decode), :69-170 (dummy opponent),
+//   :173-245 (12-channel obs), :318-442 (reward / done / info).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/inversus_hip.h"
+
+namespace inv {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kHeadWords = 8;      // per-env head record, 32 B
+constexpr int kMtStride = 640;     // u32 words per env in the MT array (624 used), 2560 B = 20 x 128-B lines
+
+// head record words
+enum { HD_P1 = 0, HD_P2 = 1, HD_FLAGS = 2, HD_STEP = 3, HD_OPP = 4, HD_MTI = 5, HD_RET_LO = 6, HD_RET_HI = 7 };
+// HD_P1 / HD_P2: x | y<<8 | ammo<<16 | reload<<24
+// HD_FLAGS: bit0 alive1, bit1 alive2, bit2 prev_alive1, bit3 prev_alive2, bits 8..15 live bullet count
+constexpr uint32_t FL_ALIVE1 = 1u, FL_ALIVE2 = 2u, FL_PREV1 = 4u, FL_PREV2 = 8u;
+
+// sticky device error bits (inv_check)
+constexpr uint32_t ERR_BAD_ACTION = 1u, ERR_BULLET_OVERFLOW = 2u;
+
+struct Dims {
+    int N, W, H, WH, K, GW;
+    int OW;          // u32 words of one packed observation bitstring: ceil(12*WH/32)
+    int F4;          // float4 stores per observation: 3*WH
+    int scr_words;   // LDS words per wave
+    int max_steps;
+};
+
+struct State {
+    uint32_t *head;      // [N][8]
+    uint32_t *grid;      // [N][GW]
+    uint16_t *bullets;   // [N][K]
+    uint32_t *mt;        // [N][kMtStride]
+    uint32_t *err;       // [1]
+    const double *prox;  // [W+H+1]: 0.002 * (1.0 - dist / (W+H)), env_wrappers.py:382, computed on the host in IEEE f64
+};
+
+struct StepArgs {
+    Dims d;
+    State s;
+    const uint8_t *mask;  // optional: step only envs with a non-zero byte
+    const uint8_t *a1;
+    const uint8_t *a2;
+    inv_step_out o;
+    uint32_t flags;
+    int opponent, hard;
+    uint32_t opp_seed;
+    uint32_t env_offset;
+    int T;               // vector steps in this launch (inv_rollout); 1 for inv_step
+};
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int rfl(int v) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)v); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// Orders this wave's LDS traffic: LDS ops of one wave execute in issue order, so the only
+// thing needed is that the compiler keeps that order.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t tile_bit(const uint32_t *g, int pos) { return (g[pos >> 5] >> (pos & 31)) & 1u; }
+
+__device__ __forceinline__ uint32_t pack_bullet(int x, int y, int dir, int owner)
+{
+    return (uint32_t)x | ((uint32_t)y << 6) | ((uint32_t)dir << 12) | ((uint32_t)owner << 14);
+}
+
+// ------------------------------------------------------------------ per-wave env context
+struct Player { int x, y, ammo, reload, alive; };
+
+struct Env {
+    Player p[2];
+    int prev1, prev2;
+    int nb;
+    int step_count;
+    uint32_t opp_ctr;
+    int mti;
+    double ep_ret;
+    uint32_t bw;         // lane i < nb: bullet i (canonical u16 packing)
+};
+
+__device__ __forceinline__ void load_env(const Dims &d, const State &s, int env, int lane, uint32_t *g, Env &e)
+{
+    uint32_t hv = lane < kHeadWords ? s.head[(size_t)env * kHeadWords + lane] : 0u;
+    for (int w = lane; w < d.GW; w += kWave) g[w] = s.grid[(size_t)env * d.GW + w];
+    uint32_t bwv = lane < d.K ? (uint32_t)s.bullets[(size_t)env * d.K + lane] : 0u;
+    uint32_t p1 = rdlane(hv, HD_P1), p2 = rdlane(hv, HD_P2), fl = rdlane(hv, HD_FLAGS);
+    e.p[0] = { (int)(p1 & 255u), (int)((p1 >> 8) & 255u), (int)((p1 >> 16) & 255u), (int)(p1 >> 24), (int)(fl & FL_ALIVE1) != 0 };
+    e.p[1] = { (int)(p2 & 255u), (int)((p2 >> 8) & 255u), (int)((p2 >> 16) & 255u), (int)(p2 >> 24), (int)(fl & FL_ALIVE2) != 0 };
+    e.prev1 = (fl & FL_PREV1) != 0;
+    e.prev2 = (fl & FL_PREV2) != 0;
+    e.nb = (int)((fl >> 8) & 255u);
+    e.step_count = (int)rdlane(hv, HD_STEP);
+    e.opp_ctr = rdlane(hv, HD_OPP);
+    e.mti = (int)rdlane(hv, HD_MTI);
+    uint64_t rb = (uint64_t)rdlane(hv, HD_RET_LO) | ((uint64_t)rdlane(hv, HD_RET_HI) << 32);
+    e.ep_ret = __longlong_as_double((long long)rb);
+    e.bw = lane < e.nb ? bwv : 0u;
+    wave_sync();
+}
+
+__device__ __forceinline__ void store_env(const Dims &d, const State &s, int env, int lane, const uint32_t *g, const Env &e)
+{
+    uint64_t rb = (uint64_t)__double_as_longlong(e.ep_ret);
+    uint32_t fl = (e.p[0].alive ? FL_ALIVE1 : 0u) | (e.p[1].alive ? FL_ALIVE2 : 0u) | (e.prev1 ? FL_PREV1 : 0u) |
+                  (e.prev2 ? FL_PREV2 : 0u) | ((uint32_t)e.nb << 8);
+    uint32_t p1 = (uint32_t)e.p[0].x | ((uint32_t)e.p[0].y << 8) | ((uint32_t)e.p[0].ammo << 16) | ((uint32_t)e.p[0].reload << 24);
+    uint32_t p2 = (uint32_t)e.p[1].x | ((uint32_t)e.p[1].y << 8) | ((uint32_t)e.p[1].ammo << 16) | ((uint32_t)e.p[1].reload << 24);
+    uint32_t hv = lane == HD_P1 ? p1 : lane == HD_P2 ? p2 : lane == HD_FLAGS ? fl : lane == HD_STEP ? (uint32_t)e.step_count
+                : lane == HD_OPP ? e.opp_ctr : lane == HD_MTI ? (uint32_t)e.mti : lane == HD_RET_LO ? (uint32_t)rb : (uint32_t)(rb >> 32);
+    if (lane < kHeadWords) s.head[(size_t)env * kHeadWords + lane] = hv;
+    for (int w = lane; w < d.GW; w += kWave) s.grid[(size_t)env * d.GW + w] = g[w];
+    if (lane < d.K) s.bullets[(size_t)env * d.K + lane] = (uint16_t)(lane < e.nb ? e.bw : 0u);
+}
+
+// ------------------------------------------------------------------ actions (core.py:249-381, 510-525)
+__device__ __forceinline__ void emit_bullet(const Dims &d, int lane, Env &e, uint32_t word, bool valid, uint32_t &err)
+{
+    if (!valid) return;
+    if (e.nb >= d.K) { err |= ERR_BULLET_OVERFLOW; return; }
+    if (lane == e.nb) e.bw = word;
+    e.nb += 1;
+}
+
+__device__ __forceinline__ void apply_action(const Dims &d, const uint32_t *g, int lane, int pid, int a, Env &e, uint32_t &err)
+{
+    Player &p = e.p[pid];
+    if (!p.alive || a == 0) return;
+    const int type = (a + 3) >> 2, dir = (a - 1) & 3;          // env_wrappers.py:24-37
+    const int dx = (dir == 1) - (dir == 3), dy = (dir == 2) - (dir == 0);
+    if (type == 1) {                                           // MOVE, core.py:249-296
+        const int nx = p.x + dx, ny = p.y + dy;
+        if (nx >= 0 && nx < d.W && ny >= 0 && ny < d.H) {
+            // walkable <=> tile != player's colour; P1 is BLACK (bit 0), P2 is WHITE (bit 1)
+            if (rfl(tile_bit(g, ny * d.W + nx)) != (uint32_t)pid) { p.x = nx; p.y = ny; }
+        }
+    } else if (type == 2) {                                    // SHOOT, core.py:298-326
+        if (p.ammo > 0) {
+            p.ammo -= 1;
+            emit_bullet(d, lane, e, pack_bullet(p.x, p.y, dir, pid), true, err);
+        }
+    } else {                                                   // CHARGE_SHOOT, core.py:328-381
+        if (p.ammo >= 3) {
+            p.ammo -= 3;
+            const int vertical = (dir & 1) == 0;               // UP / DOWN: side lanes at x-1, x+1; else y-1, y+1
+            const int ax = vertical ? p.x - 1 : p.x, ay = vertical ? p.y : p.y - 1;
+            const int bx = vertical ? p.x + 1 : p.x, by = vertical ? p.y : p.y + 1;
+            emit_bullet(d, lane, e, pack_bullet(p.x, p.y, dir, pid), true, err);
+            emit_bullet(d, lane, e, pack_bullet(ax, ay, dir, pid), ax >= 0 && ay >= 0, err);
+            emit_bullet(d, lane, e, pack_bullet(bx, by, dir, pid), bx < d.W && by < d.H, err);
+        }
+    }
+}
+
+__device__ __forceinline__ void reload(Player &p)               // core.py:383-397
+{
+    if (!p.alive) return;
+    if (p.ammo < 6) {
+        p.reload += 1;
+        if (p.reload >= 30) { p.ammo += 1; p.reload = 0; }
+    }
+}
+
+// ------------------------------------------------------------------ bullets (core.py:399-475)
+// Returns tile_diff = (#tiles turned WHITE) - (#tiles turned BLACK) of this update.
+__device__ __forceinline__ int update_bullets(const Dims &d, uint32_t *g, uint32_t *slots, int lane, Env &e)
+{
+    const int bx = (int)(e.bw & 63u), by = (int)((e.bw >> 6) & 63u), dir = (int)((e.bw >> 12) & 3u), own = (int)((e.bw >> 14) & 1u);
+    const int nx = bx + (dir == 1) - (dir == 3), ny = by + (dir == 2) - (dir == 0);
+    const bool live = lane < e.nb && nx >= 0 && nx < d.W && ny >= 0 && ny < d.H;   // :428-431
+    const int pos = live ? ny * d.W + nx : -1;
+
+    // Tile groups: a bullet meeting a different owner's bullet on its target tile vanishes
+    // (:444-449); among same-owner arrivals only the first in list order survives (:453).
+    bool cancel = false, dup = false;
+    uint64_t m = __ballot(live);
+    while (m) {
+        const int j = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        const int pj = (int)rdlane((uint32_t)pos, j);
+        const int oj = (int)rdlane((uint32_t)own, j);
+        const bool same = pos == pj;
+        cancel |= same && own != oj;
+        dup |= same && own == oj && j < lane;
+    }
+    const bool keep = live && !cancel && !dup;
+
+    // flip only tiles of the owner's colour (:458-461): P1 turns BLACK->WHITE, P2 WHITE->BLACK
+    uint32_t tb = 0u;
+    if (keep) tb = tile_bit(g, pos);
+    const bool f1 = keep && own == 0 && tb == 0u;
+    const bool f2 = keep && own == 1 && tb == 1u;
+    wave_sync();
+    if (f1) atomicOr(&g[pos >> 5], 1u << (pos & 31));
+    if (f2) atomicAnd(&g[pos >> 5], ~(1u << (pos & 31)));
+    const int tile_diff = __popcll(__ballot(f1)) - __popcll(__ballot(f2));
+
+    // kills (:464-470): a surviving bullet on an alive non-owner's tile
+    const int pos1 = e.p[0].y * d.W + e.p[0].x, pos2 = e.p[1].y * d.W + e.p[1].x;
+    if (e.p[0].alive && __ballot(keep && own == 1 && pos == pos1) != 0ull) e.p[0].alive = 0;
+    if (e.p[1].alive && __ballot(keep && own == 0 && pos == pos2) != 0ull) e.p[1].alive = 0;
+
+    // stable compaction: survivors keep list order == first-arrival order of their tiles (:473)
+    const uint64_t km = __ballot(keep);
+    const int idx = __popcll(km & ((1ull << lane) - 1ull));
+    if (keep) slots[idx] = pack_bullet(nx, ny, dir, own);
+    e.nb = __popcll(km);
+    wave_sync();
+    e.bw = lane < e.nb ? slots[lane] : 0u;
+    return tile_diff;
+}
+
+// ------------------------------------------------------------------ MT19937 (CPython random.Random, core.py:41,69-70,86-87)
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// Regenerate all 624 words (genrand_uint32's block), 64 words per pass.  Passes run in
+// index order; inside a pass every lane reads before any lane writes, which reproduces the
+// sequential recurrence exactly: word k needs OLD k, OLD k+1 (NEW word 0 for k = 623) and
+// word k+397 (OLD for k < 227, else NEW word k-227, written >= 3 passes earlier).
+__device__ inline void mt_twist(uint32_t *mtg, uint32_t *scr, int lane)
+{
+    for (int i = lane; i < 624; i += kWave) scr[i] = mtg[i];
+    wave_sync();
+    for (int base = 0; base < 624; base += kWave) {
+        const int kk = base + lane;
+        uint32_t nv = 0u;
+        if (kk < 624) {
+            const uint32_t a = scr[kk];
+            const uint32_t b = scr[kk + 1 == 624 ? 0 : kk + 1];
+            const uint32_t c = scr[kk + 397 >= 624 ? kk - 227 : kk + 397];
+            const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+            nv = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        wave_sync();
+        if (kk < 624) scr[kk] = nv;
+        wave_sync();
+    }
+    for (int i = lane; i < 624; i += kWave) mtg[i] = scr[i];
+    wave_sync();
+}
+
+// InversusEnv.reset() (core.py:55-154) + SingleInversusRLEnv.reset() bookkeeping
+// (env_wrappers.py:278-283).  scr: >= 624 LDS words.
+__device__ inline void reset_env(const Dims &d, const State &s, int env, int lane, uint32_t *g, uint32_t *scr, Env &e)
+{
+    uint32_t *mtg = s.mt + (size_t)env * kMtStride;
+    const uint32_t nx = (uint32_t)(d.W - 2), ny = (uint32_t)(d.H - 2);
+    const int kx = 32 - __clz((int)nx), ky = 32 - __clz((int)ny);       // n.bit_length()
+    int stage = 0, tries = 0, fin = 0;
+    int p1x = 0, p1y = 0, p2x = 0, p2y = 0;
+    int mti = e.mti;
+    while (!fin) {
+        if (mti >= 624) { mt_twist(mtg, scr, lane); mti = 0; }
+        const int avail = min(kWave, 624 - mti);
+        const uint32_t y = mt_temper(lane < avail ? mtg[mti + lane] : 0u);
+        int used = 0;
+        for (int i = 0; i < avail && !fin; ++i) {
+            const uint32_t v = rdlane(y, i);
+            used += 1;
+            const bool isx = (stage & 1) == 0;
+            const uint32_t r = v >> (32 - (isx ? kx : ky));                // getrandbits(k)
+            if (r < (isx ? nx : ny)) {                                     // _randbelow rejection loop
+                const int val = 1 + (int)r;                                // randint(1, n)
+                if (stage == 0) { p1x = val; stage = 1; }
+                else if (stage == 1) { p1y = val; stage = 2; }
+                else if (stage == 2) { p2x = val; stage = 3; }
+                else {
+                    p2y = val;
+                    tries += 1;
+                    const int dist = abs(p2x - p1x) + abs(p2y - p1y);
+                    if (dist > 4 || tries == 20) fin = 1;                  // :85-90, last try kept regardless
+                    else stage = 2;
+                }
+            }
+        }
+        mti += used;
+    }
+    e.mti = mti;
+
+    // grid: BLACK everywhere, WHITE plus at (1,1) (config.py:20-56), P2 plus WHITE, P1 plus WHITE,
+    // then P2 plus BLACK (core.py:96-146)  ==  (plus(1,1) | plus(P1)) & ~plus(P2)
+    wave_sync();
+    for (int w = lane; w < d.GW; w += kWave) {
+        uint32_t word = 0u, clr = 0u;
+        const int cx[3] = { 1, p1x, p2x }, cy[3] = { 1, p1y, p2y };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int x = cx[c] + (q == 1) - (q == 2), yy = cy[c] + (q == 3) - (q == 4);
+                if (x >= 0 && x < d.W && yy >= 0 && yy < d.H) {
+                    const int pos = yy * d.W + x;
+                    if ((pos >> 5) == w) {
+                        if (c < 2) word |= 1u << (pos & 31); else clr |= 1u << (pos & 31);
+                    }
+                }
+            }
+        }
+        g[w] = word & ~clr;
+    }
+    wave_sync();
+    e.p[0] = { p1x, p1y, 6, 0, 1 };
+    e.p[1] = { p2x, p2y, 6, 0, 1 };
+    e.nb = 0;
+    e.bw = 0u;
+    e.step_count = 0;
+    e.ep_ret = 0.0;
+    e.prev1 = e.prev2 = 1;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 + dummy opponent (env_wrappers.py:69-170)
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return { c0, c1, c2, c3 };
+}
+
+constexpr uint32_t kTagDummy = 0x44554d59u, kTagAction = 0x4143544eu, kKey1 = 0x1234abcdu;
+
+// random.shuffle's loop on a 4-element list kept as packed nibbles (element i in bits 4i..4i+3):
+// for i = 3..1: j = randbelow(i+1); swap(i, j), with randbelow(m) = mulhi(word, m).
+__device__ __forceinline__ uint32_t set_nibble(uint32_t p, int k, uint32_t v) { return (p & ~(15u << (4 * k))) | (v << (4 * k)); }
+
+__device__ __forceinline__ uint32_t fy_perm4(uint32_t w0, uint32_t w1, uint32_t w2)
+{
+    uint32_t perm = 0x3210u;
+    const uint32_t ws[3] = { w0, w1, w2 };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = 3 - k;
+        const int j = (int)__umulhi(ws[k], (uint32_t)(i + 1));
+        const uint32_t vi = (perm >> (4 * i)) & 15u, vj = (perm >> (4 * j)) & 15u;
+        perm = set_nibble(perm, i, vj);
+        perm = set_nibble(perm, j, vi);
+    }
+    return perm;
+}
+
+__device__ __forceinline__ uint32_t apply_perm4(uint32_t list, uint32_t perm)
+{
+    uint32_t t = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t |= ((list >> (4 * ((perm >> (4 * i)) & 15u))) & 15u) << (4 * i);
+    return t;
+}
+
+__device__ inline int dummy_action(const Dims &d, const uint32_t *g, const Env &e, int hard, uint32_t seed, uint32_t genv, uint32_t ctr)
+{
+    const Player &p1 = e.p[0], &p2 = e.p[1];
+    if (!p2.alive) return 0;                                               // :77-78
+    const U4 x = philox4x32(ctr, genv, 0u, kTagDummy, seed, kKey1);
+    const U4 y = philox4x32(ctr, genv, 1u, kTagDummy, seed, kKey1);
+    const U4 z = philox4x32(ctr, genv, 2u, kTagDummy, seed, kKey1);
+    const double u0 = (double)x.x * (1.0 / 4294967296.0), u1 = (double)x.y * (1.0 / 4294967296.0),
+                 u2 = (double)x.z * (1.0 / 4294967296.0);
+    const double shoot_prob = hard ? 0.2 : 0.0, random_move_prob = hard ? 0.05 : 0.0, move_prob = 0.001;   // :81-89
+
+    // walkable-for-P2 mask over directions (in bounds and tile != WHITE), :116-118 etc.
+    uint32_t walk = 0u;
+#pragma unroll
+    for (int dir = 0; dir < 4; ++dir) {
+        const int nx = p2.x + (dir == 1) - (dir == 3), ny = p2.y + (dir == 2) - (dir == 0);
+        if (nx >= 0 && nx < d.W && ny >= 0 && ny < d.H && rfl(tile_bit(g, ny * d.W + nx)) == 0u) walk |= 1u << dir;
+    }
+
+    const bool x_al = p2.x == p1.x, y_al = p2.y == p1.y;
+    if (u0 < shoot_prob && p2.ammo > 0 && (x_al || y_al)) {                 // :96-101
+        if (x_al) return 5 + (p1.y < p2.y ? 0 : 2);
+        return 5 + (p1.x < p2.x ? 3 : 1);
+    }
+    uint32_t dirs = 0u | (2u << 4) | (3u << 8) | (1u << 12);               // [UP, DOWN, LEFT, RIGHT], :104
+    if (u1 < random_move_prob) {                                           // :105-119
+        dirs = apply_perm4(dirs, fy_perm4(x.w, y.x, y.y));
+        const int c = (int)(dirs & 15u);
+        if ((walk >> c) & 1u) return 1 + c;
+    }
+    if (!hard) {                                                           // :122-124
+        if (u2 > move_prob) return 0;
+    }
+    const int dx = p1.x - p2.x, dy = p1.y - p2.y;                          // :127-138
+    int c0 = -1, c1 = -1;
+    if (dx != 0) c0 = dx > 0 ? 1 : 3;
+    if (dy != 0) { const int c = dy > 0 ? 2 : 0; if (c0 < 0) c0 = c; else c1 = c; }
+    if (c1 >= 0 && __umulhi(y.z, 2u) == 0u) { const int t = c0; c0 = c1; c1 = t; }
+    if (c0 >= 0 && ((walk >> c0) & 1u)) return 1 + c0;                     // :140-152
+    if (c1 >= 0 && ((walk >> c1) & 1u)) return 1 + c1;
+    dirs = apply_perm4(dirs, fy_perm4(z.x, z.y, z.z));                      // :155-168
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (int)((dirs >> (4 * i)) & 15u);
+        if ((walk >> c) & 1u) return 1 + c;
+    }
+    return 0;                                                              // :170
+}
+
+// ------------------------------------------------------------------ observation (env_wrappers.py:173-245)
+// f32(k / 6) for k = 0..6, folded at compile time (IEEE f64 divide, then one rounding to f32) -- the values
+// `player.ammo / MAX_AMMO` takes in env_wrappers.py:239-240.  Other ammo values exist only via inv_set_state.
+__constant__ float kSixths[7] = { 0.0f, (float)(1.0 / 6.0), (float)(2.0 / 6.0), (float)(3.0 / 6.0),
+                                  (float)(4.0 / 6.0), (float)(5.0 / 6.0), 1.0f };
+
+// 32 bits of a WH-bit string starting at bit `start` (zero outside [0, WH)); the string is
+// the grid (invert = false) or its complement (invert = true).
+__device__ __forceinline__ uint32_t grid_window(const uint32_t *g, int GW, uint32_t lastmask, int start, bool invert)
+{
+    const int sidx = start >> 5, sh = start & 31;
+    uint32_t lo = 0u, hi = 0u;
+    if (sidx >= 0 && sidx < GW) { lo = invert ? ~g[sidx] : g[sidx]; if (sidx == GW - 1) lo &= lastmask; }
+    if (sidx + 1 >= 0 && sidx + 1 < GW) { hi = invert ? ~g[sidx + 1] : g[sidx + 1]; if (sidx + 1 == GW - 1) hi &= lastmask; }
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+}
+
+// Render player `pid`'s 12-channel observation of the current state.  The 12*W*H floats are
+// 0/1, so the wave first assembles them as ONE packed bitstring in LDS (channels 0/1 by a
+// funnel-shifted copy of the grid words, channels 2..11 by per-lane LDS OR of single bits),
+// then every lane expands nibbles to float4 and streams them out: consecutive lanes write
+// consecutive 16 B, 1 KiB per wave store instruction.
+__device__ inline void render_obs(const Dims &d, const uint32_t *g, uint32_t *ob, int lane, int pid, const Env &e,
+                                  float *__restrict__ obs_env, float *__restrict__ extra_env)
+{
+    const int WH = d.WH;
+    const uint32_t lastmask = (WH & 31) ? ((1u << (WH & 31)) - 1u) : 0xffffffffu;
+    for (int w = lane; w < d.OW; w += kWave) {
+        const int lo = w * 32;
+        uint32_t word = 0u;
+        if (lo < 2 * WH) word = grid_window(g, d.GW, lastmask, lo, true) | grid_window(g, d.GW, lastmask, lo - WH, false);
+        ob[w] = word;
+    }
+    wave_sync();
+    // select by value: a runtime index into e.p[] would push the context to scratch
+    const Player me = pid ? e.p[1] : e.p[0], en = pid ? e.p[0] : e.p[1];
+    if (lane == 0 && me.alive && me.x < d.W && me.y < d.H) { const int b = 2 * WH + me.y * d.W + me.x; atomicOr(&ob[b >> 5], 1u << (b & 31)); }
+    if (lane == 1 && en.alive && en.x < d.W && en.y < d.H) { const int b = 3 * WH + en.y * d.W + en.x; atomicOr(&ob[b >> 5], 1u << (b & 31)); }
+    {
+        const int bx = (int)(e.bw & 63u), by = (int)((e.bw >> 6) & 63u), dir = (int)((e.bw >> 12) & 3u), own = (int)((e.bw >> 14) & 1u);
+        if (lane < e.nb && bx < d.W && by < d.H) {                          // :224-235
+            const int b = ((own == pid ? 4 : 8) + dir) * WH + by * d.W + bx;
+            atomicOr(&ob[b >> 5], 1u << (b & 31));
+        }
+    }
+    wave_sync();
+    float4 *dst = reinterpret_cast<float4 *>(obs_env);
+    for (int j = lane; j < d.F4; j += kWave) {
+        const uint32_t nib = ob[j >> 3] >> ((j & 7) * 4);
+        float4 v;
+        v.x = (nib & 1u) ? 1.0f : 0.0f;
+        v.y = (nib & 2u) ? 1.0f : 0.0f;
+        v.z = (nib & 4u) ? 1.0f : 0.0f;
+        v.w = (nib & 8u) ? 1.0f : 0.0f;
+        dst[j] = v;
+    }
+    if (extra_env && lane < 4) {                                            // :238-243: f32(ammo / 6) computed in f64
+        const Player &q = (lane & 1) ? en : me;
+        float val;
+        if (lane < 2) val = !q.alive ? 0.0f : (q.ammo <= 6 ? kSixths[q.ammo] : (float)((double)q.ammo / 6.0));
+        else val = q.alive ? 1.0f : 0.0f;
+        extra_env[lane] = val;
+    }
+    wave_sync();
+}
+
+}  // namespace inv

@@ -1,0 +1,236 @@
+"""DeviceEnvBatch: N Inversus envs resident in HBM, stepped through the C ABI.
+
+Thin host plumbing only: torch supplies device buffers and the current HIP stream; every
+computation happens in libinversus_hip.so (csrc/).  All methods are asynchronous on the
+current torch stream unless they return host data.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class StepResult:
+    """Device tensors of one vector step (or of T steps for rollout(); leading dim T)."""
+    __slots__ = ("obs", "extra", "obs_p2", "extra_p2", "reward", "reward64", "done", "info_flags",
+                 "episode_steps", "episode_return")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+class DeviceEnvBatch:
+    def __init__(self, num_envs, width=15, height=10, max_bullets=16, max_episode_steps=500,
+                 opponent="dummy", difficulty="easy", device=None, opp_seed=0, env_offset=0):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("inversus_reinforcement_learning_amd needs a ROCm GPU (torch.cuda is unavailable); "
+                               "there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device in (None, "cuda") else torch.device(device)
+        if opponent not in ("dummy", "selfplay"):
+            raise ValueError(f"Unknown opponent_type: {opponent}")            # env_wrappers.py:316
+        if difficulty not in ("easy", "hard"):
+            difficulty = "hard"                                             # env_wrappers.py:81-89: anything else is the hard branch
+        self.num_envs, self.W, self.H, self.K = int(num_envs), int(width), int(height), int(max_bullets)
+        self.GW = (self.W * self.H + 31) // 32
+        self.opponent, self.difficulty = opponent, difficulty
+        self.max_episode_steps = int(max_episode_steps)
+        self.env_offset = int(env_offset)
+        cfg = L.InvConfig(self.num_envs, self.W, self.H, self.K, self.max_episode_steps,
+                          L.INV_OPP_DUMMY if opponent == "dummy" else L.INV_OPP_EXTERNAL,
+                          L.INV_HARD if difficulty == "hard" else L.INV_EASY,
+                          self.device.index or 0, int(opp_seed) & 0xFFFFFFFF, self.env_offset)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_create(C.byref(cfg), C.byref(h)), self.lib)
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.inv_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ buffers
+    def _new(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def obs_shape(self, lead=()):
+        return tuple(lead) + (self.num_envs, 12, self.H, self.W)
+
+    def _as_actions(self, a, lead=()):
+        if a is None:
+            return None
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=torch.uint8).contiguous()
+        else:
+            arr = np.asarray(a)
+            if arr.size and (arr.min() < 0 or arr.max() > 12):
+                bad = int(arr.reshape(-1)[(arr.reshape(-1) < 0) | (arr.reshape(-1) > 12)][0])
+                raise ValueError(f"Invalid action_id: {bad}, must be 0-12")  # env_wrappers.py:66
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8)).to(self.device)
+        if tuple(t.shape) != tuple(lead) + (self.num_envs,):
+            raise ValueError(f"actions must have shape {tuple(lead) + (self.num_envs,)}, got {tuple(t.shape)}")
+        return t
+
+    # ------------------------------------------------------------------ control
+    def seed(self, seeds, mask=None):
+        s = np.ascontiguousarray(seeds, dtype=np.int64)
+        assert s.shape == (self.num_envs,)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_seed_masked(self.h, s.ctypes.data_as(C.c_void_p),
+                                                 None if m is None else m.ctypes.data_as(C.c_void_p), _stream()), self.lib)
+            torch.cuda.current_stream().synchronize()      # seeds staging buffer is reused
+
+    def reset(self, mask=None):
+        m = None if mask is None else torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_reset(self.h, _ptr(m), _stream()), self.lib)
+
+    def check(self):
+        """Synchronise and raise the sticky device error, if any (bad action id / bullet overflow)."""
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_check(self.h, _stream()), self.lib)
+
+    # ------------------------------------------------------------------ step / render
+    def _alloc_out(self, lead, obs, obs_p2, reward64, out):
+        if out is not None:
+            return out
+        n = self.num_envs
+        r = StepResult(
+            obs=self._new(self.obs_shape(lead), torch.float32) if obs else None,
+            extra=self._new(tuple(lead) + (n, 4), torch.float32) if obs else None,
+            obs_p2=self._new(self.obs_shape(lead), torch.float32) if obs_p2 else None,
+            extra_p2=self._new(tuple(lead) + (n, 4), torch.float32) if obs_p2 else None,
+            reward=self._new(tuple(lead) + (n,), torch.float32),
+            reward64=self._new(tuple(lead) + (n,), torch.float64) if reward64 else None,
+            done=self._new(tuple(lead) + (n,), torch.uint8),
+            info_flags=self._new(tuple(lead) + (n,), torch.uint8),
+            episode_steps=self._new(tuple(lead) + (n,), torch.int32),
+            episode_return=self._new(tuple(lead) + (n,), torch.float64),
+        )
+        return r
+
+    @staticmethod
+    def _c_out(r):
+        return L.InvStepOut(*[_ptr(getattr(r, k)) for k in StepResult.__slots__])
+
+    def step(self, a1, a2=None, auto_reset=False, flags=L.INV_STEP_DEFAULT, obs=True, obs_p2=False,
+             reward64=False, out=None, mask=None):
+        """One vector step.  a2=None uses the device dummy opponent (opponent="dummy" only)."""
+        a1t, a2t = self._as_actions(a1), self._as_actions(a2)
+        r = self._alloc_out((), obs, obs_p2, reward64, out)
+        co = self._c_out(r)
+        fl = int(flags) | (L.INV_STEP_AUTO_RESET if auto_reset else 0)
+        with torch.cuda.device(self.device):
+            if mask is None:
+                rc = self.lib.inv_step(self.h, _ptr(a1t), _ptr(a2t), fl, C.byref(co), _stream())
+            else:
+                m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+                rc = self.lib.inv_step_masked(self.h, _ptr(m), _ptr(a1t), _ptr(a2t), fl, C.byref(co), _stream())
+        L.raise_for(rc, self.lib)
+        return r
+
+    def rollout(self, a1, a2=None, obs=True, obs_p2=False, reward64=False, out=None):
+        """T vector steps in one launch with pre-supplied actions a1[T, N] (always auto-resets)."""
+        T = int(a1.shape[0])
+        a1t, a2t = self._as_actions(a1, (T,)), self._as_actions(a2, (T,))
+        r = self._alloc_out((T,), obs, obs_p2, reward64, out)
+        co = self._c_out(r)
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_rollout(self.h, T, _ptr(a1t), _ptr(a2t), C.byref(co), _stream()), self.lib)
+        return r
+
+    def render(self, player=0, out=None):
+        """build_observation for every env: (grid[N,12,H,W], extra[N,4]) device tensors."""
+        if out is None:
+            out = (self._new(self.obs_shape(), torch.float32), self._new((self.num_envs, 4), torch.float32))
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_render_obs(self.h, int(player), _ptr(out[0]), _ptr(out[1]), _stream()), self.lib)
+        return out
+
+    def uniform_actions(self, seed, t, out=None):
+        if out is None:
+            out = self._new((self.num_envs,), torch.uint8)
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_uniform_actions(_ptr(out), self.num_envs, int(seed) & 0xFFFFFFFF,
+                                                     self.env_offset, int(t) & 0xFFFFFFFF, _stream()), self.lib)
+        return out
+
+    # ------------------------------------------------------------------ state dump / poke
+    _STATE_FIELDS = (("grid", torch.int32, lambda s: (s.num_envs, s.GW), np.uint32),
+                     ("players", torch.int32, lambda s: (s.num_envs, 2, 5), np.int32),
+                     ("nbullets", torch.int32, lambda s: (s.num_envs,), np.int32),
+                     ("bullets", torch.int16, lambda s: (s.num_envs, s.K), np.uint16),
+                     ("step_count", torch.int32, lambda s: (s.num_envs,), np.int32),
+                     ("episode_return", torch.float64, lambda s: (s.num_envs,), np.float64),
+                     ("prev_alive", torch.uint8, lambda s: (s.num_envs, 2), np.uint8),
+                     ("opp_ctr", torch.int32, lambda s: (s.num_envs,), np.uint32),
+                     ("mt", torch.int32, lambda s: (s.num_envs, 624), np.uint32),
+                     ("mt_index", torch.int32, lambda s: (s.num_envs,), np.int32))
+
+    def get_state(self, fields=None):
+        """Canonical state as numpy arrays (see include/inversus_hip.h); synchronises."""
+        want = [f for f in self._STATE_FIELDS if (fields is None and f[0] != "mt") or (fields and f[0] in fields)]
+        bufs = {name: self._new(shape(self), tdt) for name, tdt, shape, _ in want}
+        view = L.InvStateView(**{name: _ptr(t) for name, t in bufs.items()})
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_get_state(self.h, C.byref(view), _stream()), self.lib)
+        return {name: bufs[name].cpu().numpy().view(npdt) for name, _, _, npdt in want}
+
+    def set_state(self, **arrays):
+        """Overwrite the given canonical state arrays (full [N, ...] arrays) on the device."""
+        bufs = {}
+        for name, tdt, shape, npdt in self._STATE_FIELDS:
+            if name in arrays:
+                a = np.ascontiguousarray(arrays[name]).astype(npdt, copy=False)
+                if a.shape != shape(self):
+                    raise ValueError(f"{name}: expected shape {shape(self)}, got {a.shape}")
+                signed = a.view({np.uint32: np.int32, np.uint16: np.int16}.get(npdt, npdt))
+                bufs[name] = torch.from_numpy(np.ascontiguousarray(signed)).to(self.device)
+        unknown = set(arrays) - {f[0] for f in self._STATE_FIELDS}
+        if unknown:
+            raise ValueError(f"unknown state fields: {sorted(unknown)}")
+        view = L.InvStateView(**{name: _ptr(t) for name, t in bufs.items()})
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_set_state(self.h, C.byref(view), _stream()), self.lib)
+            torch.cuda.current_stream().synchronize()      # keep the staging tensors alive until consumed
+
+
+def gae(rewards, values, dones, gamma=0.99, lam=0.95, last_value=None, layout="per_env"):
+    """GAE / returns on device (ppo_agent.py:127-157), strict f32.  rewards/values f32 [T, N],
+    dones bool/u8 [T, N].  layout: "per_env" or "reference_flat"."""
+    lib = L.load()
+    r = rewards.contiguous().float()
+    v = values.contiguous().float()
+    d = dones.contiguous().to(torch.uint8)
+    if r.dim() == 1:
+        r, v, d = r[:, None], v[:, None], d[:, None]
+    T, N = r.shape
+    adv, ret = torch.empty_like(r), torch.empty_like(r)
+    lv = None
+    if last_value is not None:
+        lv = torch.as_tensor(last_value, dtype=torch.float32, device=r.device).reshape(-1).contiguous()
+    code = {"per_env": L.INV_GAE_PER_ENV, "reference_flat": L.INV_GAE_REFERENCE_FLAT}[layout]
+    # gamma * lam is a Python-float (f64) product rounded once to f32, like the reference's
+    # `self.gamma * self.lam * last_gae` under NumPy >= 2 weak-scalar promotion
+    gl = float(np.float32(float(gamma) * float(lam)))
+    with torch.cuda.device(r.device):
+        rc = lib.inv_gae(_ptr(r), _ptr(v), _ptr(d), T, N, float(np.float32(gamma)), gl, _ptr(lv), code,
+                         _ptr(adv), _ptr(ret), _stream())
+    L.raise_for(rc, lib)
+    return adv, ret
