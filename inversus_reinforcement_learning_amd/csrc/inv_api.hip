@@ -15,30 +15,51 @@ using namespace inv;
 
 // =================================================================== kernels
 
+// LDS slice of a wave: [nibble table 64][grid GW][bullet slots K][scratch >= 624]
+template <class D>
+struct WaveLds {
+    uint32_t *tabw, *g, *slots, *scr;
+    __device__ WaveLds(const D &d, uint32_t *lds, int wv)
+    {
+        tabw = lds + wv * d.scr_words;
+        g = tabw + kTabWords;
+        slots = g + d.GW;
+        scr = slots + d.K;
+    }
+};
+
 // MultiEnvRunner.step for every env of the shard, T times (T = 1: inv_step; T > 1: inv_rollout).
+template <class D, bool SINGLE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
 {
     extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1), wv = rfl((int)(threadIdx.x >> 6));   // wave index: uniform -> SGPR
     const int env = blockIdx.x * kWavesPerBlock + wv;
-    if (env >= a.d.N) return;                       // wave-uniform; no block barriers below
+    const int N = a.d.N;
+    if (env >= N) return;                           // wave-uniform; no block barriers below
     if (a.mask && rfl((int)a.mask[env]) == 0) return;
-    const Dims &d = a.d;
-    uint32_t *g = lds + wv * d.scr_words;           // [GW]   tile grid bitstring
-    uint32_t *slots = g + d.GW;                     // [K]    bullet compaction slots
-    uint32_t *scr = slots + d.K;                    // [>=624] obs bitstring / MT twist scratch
+    const D d(a.d);
+    const WaveLds<D> L(d, lds, wv);
+    uint32_t *g = L.g;
+    const float4 *tab = reinterpret_cast<const float4 *>(L.tabw);
 
+    // issue the action loads of the first step together with the state loads
+    uint32_t act1v = a.a1[env], act2v = a.a2 ? (uint32_t)a.a2[env] : 0u;
+    init_nibble_table(reinterpret_cast<float *>(L.tabw), lane);
     Env e;
     load_env(d, a.s, env, lane, g, e);
     uint32_t err = 0u;
     const size_t obs_stride = (size_t)12 * d.WH;
+    const bool full = (a.flags & INV_STEP_DEFAULT) == INV_STEP_DEFAULT;
 
-    for (int t = 0; t < a.T; ++t) {
-        const size_t idx = (size_t)t * d.N + env;
-        const int act1 = rfl((int)a.a1[idx]);
+    const int T = SINGLE ? 1 : a.T;
+    for (int t = 0; t < T; ++t) {
+        const size_t idx = (size_t)t * N + env;
+        if (t > 0) { act1v = a.a1[idx]; act2v = a.a2 ? (uint32_t)a.a2[idx] : 0u; }
+        const int act1 = rfl((int)act1v);
         int act2;
         if (a.a2) {
-            act2 = rfl((int)a.a2[idx]);
+            act2 = rfl((int)act2v);
         } else {
             act2 = rfl(dummy_action(d, g, e, a.hard, a.opp_seed, a.env_offset + (uint32_t)env, e.opp_ctr));
             e.opp_ctr += 1u;
@@ -50,15 +71,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
         if (bad) err |= ERR_BAD_ACTION;
 
         if (!bad) {
-            if (a.flags & INV_PHASE_ACTIONS) {      // core.py:510-525: P1 then P2
+            if (full || (a.flags & INV_PHASE_ACTIONS)) {      // core.py:510-525: P1 then P2
                 apply_action(d, g, lane, 0, act1, e, err);
                 apply_action(d, g, lane, 1, act2, e, err);
             }
-            if (a.flags & INV_PHASE_RELOAD) { reload(e.p[0]); reload(e.p[1]); }            // :528
+            if (full || (a.flags & INV_PHASE_RELOAD)) { reload(e.p[0]); reload(e.p[1]); }            // :528
             int tile_diff = 0;
-            if (a.flags & INV_PHASE_BULLETS) tile_diff = update_bullets(d, g, slots, lane, e);   // :531
+            if (full || (a.flags & INV_PHASE_BULLETS)) tile_diff = update_bullets(d, g, L.slots, lane, e);   // :531
 
-            if (a.flags & INV_PHASE_WRAPPER) {      // env_wrappers.py:333-442, f64 adds in the reference's order
+            if (full || (a.flags & INV_PHASE_WRAPPER)) {      // env_wrappers.py:333-442, f64 adds in the reference's order
                 e.step_count += 1;
                 const Player &p1 = e.p[0], &p2 = e.p[1];
                 if (tile_diff > 0) reward += (double)tile_diff * 0.01;
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
                 }
                 e.prev1 = p1.alive;
                 e.prev2 = p2.alive;
-                if (e.step_count >= d.max_steps) {
+                if (e.step_count >= a.d.max_steps) {
                     done = 1;
                     if (!over) reward -= 2.0;
                 }
@@ -105,43 +126,55 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
             if (a.o.episode_return) a.o.episode_return[idx] = e.ep_ret;
         }
 
-        if (done && (a.flags & INV_STEP_AUTO_RESET)) reset_env(d, a.s, env, lane, g, scr, e);   // training.py:148-151
+        if (done && (a.flags & INV_STEP_AUTO_RESET)) reset_env(d, a.s, env, lane, g, L.scr, e);   // training.py:148-151
 
-        if (a.o.obs) render_obs(d, g, scr, lane, 0, e, a.o.obs + idx * obs_stride, a.o.extra ? a.o.extra + idx * 4 : nullptr);
-        if (a.o.obs_p2) render_obs(d, g, scr, lane, 1, e, a.o.obs_p2 + idx * obs_stride, a.o.extra_p2 ? a.o.extra_p2 + idx * 4 : nullptr);
+        if (a.o.obs) render_obs(d, g, L.scr, tab, lane, 0, e, a.o.obs + idx * obs_stride, a.o.extra ? a.o.extra + idx * 4 : nullptr);
+        if (a.o.obs_p2) render_obs(d, g, L.scr, tab, lane, 1, e, a.o.obs_p2 + idx * obs_stride, a.o.extra_p2 ? a.o.extra_p2 + idx * 4 : nullptr);
     }
 
     store_env(d, a.s, env, lane, g, e);
     if (err && lane == 0) atomicOr(a.s.err, err);
 }
 
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_reset(Dims d, State s, const uint8_t *mask)
+template <class D>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_reset(Dims dd, State s, const uint8_t *mask)
 {
     extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1), wv = rfl((int)(threadIdx.x >> 6));
     const int env = blockIdx.x * kWavesPerBlock + wv;
-    if (env >= d.N) return;
+    if (env >= dd.N) return;
     if (mask && rfl((int)mask[env]) == 0) return;
-    uint32_t *g = lds + wv * d.scr_words;
-    uint32_t *scr = g + d.GW + d.K;
+    const D d(dd);
+    const WaveLds<D> L(d, lds, wv);
     Env e;
-    load_env(d, s, env, lane, g, e);
-    reset_env(d, s, env, lane, g, scr, e);
-    store_env(d, s, env, lane, g, e);
+    load_env(d, s, env, lane, L.g, e);
+    reset_env(d, s, env, lane, L.g, L.scr, e);
+    store_env(d, s, env, lane, L.g, e);
 }
 
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims d, State s, int player, float *obs, float *extra)
+template <class D>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims dd, State s, int player, float *obs, float *extra)
 {
     extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1), wv = rfl((int)(threadIdx.x >> 6));
     const int env = blockIdx.x * kWavesPerBlock + wv;
-    if (env >= d.N) return;
-    uint32_t *g = lds + wv * d.scr_words;
-    uint32_t *scr = g + d.GW + d.K;
+    if (env >= dd.N) return;
+    const D d(dd);
+    const WaveLds<D> L(d, lds, wv);
+    init_nibble_table(reinterpret_cast<float *>(L.tabw), lane);
     Env e;
-    load_env(d, s, env, lane, g, e);
-    render_obs(d, g, scr, lane, player, e, obs + (size_t)env * 12 * d.WH, extra ? extra + (size_t)env * 4 : nullptr);
+    load_env(d, s, env, lane, L.g, e);
+    render_obs(d, L.g, L.scr, reinterpret_cast<const float4 *>(L.tabw), lane, player, e,
+               obs + (size_t)env * 12 * d.WH, extra ? extra + (size_t)env * 4 : nullptr);
 }
+
+// Pick the dims policy: the two configurations of BASELINE.json get fully folded code.
+#define INV_DISPATCH_DIMS(dims, ...)                                                      \
+    do {                                                                                  \
+        if ((dims).W == 15 && (dims).H == 10 && (dims).K == 16) { using DT = StaticDims<15, 10, 16>; __VA_ARGS__; } \
+        else if ((dims).W == 32 && (dims).H == 32 && (dims).K == 16) { using DT = StaticDims<32, 32, 16>; __VA_ARGS__; } \
+        else { using DT = RuntimeDims; __VA_ARGS__; }                                     \
+    } while (0)
 
 // random.Random(seed): init_by_array(key) of CPython's _randommodule.c, one thread per env.
 // key[env] = {low word, high word of abs(seed)}; key length 2 iff the high word is non-zero.
@@ -322,8 +355,7 @@ int inv_create(const inv_config *cfg, inv_handle **out)
     d.GW = (d.WH + 31) / 32;
     d.OW = (12 * d.WH + 31) / 32;
     d.F4 = 3 * d.WH;
-    const int scratch = d.OW > 624 ? d.OW : 624;
-    d.scr_words = (d.GW + d.K + scratch + 3) & ~3;
+    d.scr_words = scr_words_for(d.GW, d.K, d.OW);     // table + grid + slots + scratch, 16-B multiple
     d.max_steps = cfg->max_episode_steps;
     h->lds_bytes = d.scr_words * 4 * kWavesPerBlock;
 
@@ -401,8 +433,8 @@ int inv_seed(inv_handle *h, const int64_t *seeds_host, void *stream) { return in
 int inv_reset(inv_handle *h, const uint8_t *mask, void *stream)
 {
     if (!h) return fail(INV_ERR_BAD_ARG, "inv_reset: NULL handle");
-    hipLaunchKernelGGL(k_reset, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes, (hipStream_t)stream,
-                       h->d, h->s, mask);
+    INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL(k_reset<DT>, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes,
+                                               (hipStream_t)stream, h->d, h->s, mask));
     HIP_TRY(hipGetLastError());
     return INV_OK;
 }
@@ -423,7 +455,12 @@ static int launch_step(inv_handle *h, int T, const uint8_t *mask, const uint8_t 
     a.opp_seed = h->cfg.opp_seed;
     a.env_offset = (uint32_t)h->cfg.env_offset;
     a.T = T;
-    hipLaunchKernelGGL(k_step, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes, (hipStream_t)stream, a);
+    if (T == 1)
+        INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL((k_step<DT, true>), dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock),
+                                                   h->lds_bytes, (hipStream_t)stream, a));
+    else
+        INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL((k_step<DT, false>), dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock),
+                                                   h->lds_bytes, (hipStream_t)stream, a));
     HIP_TRY(hipGetLastError());
     return INV_OK;
 }
@@ -449,8 +486,8 @@ int inv_render_obs(inv_handle *h, int32_t player, float *obs, float *extra, void
 {
     if (!h || !obs) return fail(INV_ERR_BAD_ARG, "inv_render_obs: NULL argument");
     if (player != 0 && player != 1) return fail(INV_ERR_BAD_ARG, "Invalid player ID: %d", player);   // core.py:198
-    hipLaunchKernelGGL(k_render, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes, (hipStream_t)stream,
-                       h->d, h->s, player, obs, extra);
+    INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL(k_render<DT>, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes,
+                                               (hipStream_t)stream, h->d, h->s, player, obs, extra));
     HIP_TRY(hipGetLastError());
     return INV_OK;
 }

@@ -1,10 +1,17 @@
 // inv_device.h -- device-side building blocks of the gfx950 Inversus env kernels.
 //
 // Execution model: ONE WAVEFRONT (64 lanes) PER ENV.  Per-env scalars (players, ammo,
-// counters, reward) are wave-uniform and live in SGPRs via readfirstlane; lane i < K owns
-// bullet slot i; the tile grid (1 bit per tile, row-major bitstring) and the packed
-// observation bitstring are staged in the wave's private LDS slice.  No workgroup
-// barriers anywhere: waves of a block never communicate, only lanes of one wave do.
+// counters, reward) are wave-uniform and live in SGPRs (the wave index is made uniform with
+// readfirstlane); lane i < K owns bullet slot i; the tile grid (1 bit per tile, row-major
+// bitstring) and the packed observation bitstring are staged in the wave's private LDS
+// slice.  No workgroup barriers anywhere: waves of a block never communicate, only lanes of
+// one wave do.
+//
+// The kernels are instruction-issue bound before they are HBM bound (measured: ~1700
+// instructions per env-step in the first, runtime-dimensioned version), so every function
+// is templated on a dims policy: StaticDims<W,H,K> folds all index arithmetic, loop bounds
+// and masks for the configurations that matter (15x10 and 32x32), RuntimeDims serves any
+// other 3..64 x 3..64 grid with the same code.
 //
 // Reference semantics restated here (file:line relative to the reference checkout):
 //   inversus/core.py:55-154 (reset), :249-381 (move / shoot / wide shot), :383-397
@@ -24,6 +31,7 @@ constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kHeadWords = 8;      // per-env head record, 32 B
 constexpr int kMtStride = 640;     // u32 words per env in the MT array (624 used), 2560 B = 20 x 128-B lines
+constexpr int kTabWords = 64;      // nibble -> float4 table, 16 x 16 B
 
 // head record words
 enum { HD_P1 = 0, HD_P2 = 1, HD_FLAGS = 2, HD_STEP = 3, HD_OPP = 4, HD_MTI = 5, HD_RET_LO = 6, HD_RET_HI = 7 };
@@ -34,13 +42,31 @@ constexpr uint32_t FL_ALIVE1 = 1u, FL_ALIVE2 = 2u, FL_PREV1 = 4u, FL_PREV2 = 8u;
 // sticky device error bits (inv_check)
 constexpr uint32_t ERR_BAD_ACTION = 1u, ERR_BULLET_OVERFLOW = 2u;
 
-struct Dims {
+// ------------------------------------------------------------------ dims policies
+struct Dims {            // runtime description (host fills it; also the RuntimeDims payload)
     int N, W, H, WH, K, GW;
-    int OW;          // u32 words of one packed observation bitstring: ceil(12*WH/32)
-    int F4;          // float4 stores per observation: 3*WH
-    int scr_words;   // LDS words per wave
+    int OW;              // u32 words of one packed observation bitstring: ceil(12*WH/32)
+    int F4;              // float4 stores per observation: 3*WH
+    int scr_words;       // LDS words per wave
     int max_steps;
 };
+
+template <int W_, int H_, int K_>
+struct StaticDims {
+    static constexpr int W = W_, H = H_, WH = W_ * H_, K = K_, GW = (W_ * H_ + 31) / 32;
+    static constexpr int OW = (12 * W_ * H_ + 31) / 32, F4 = 3 * W_ * H_;
+    static constexpr int SCR = (OW > 624 ? OW : 624);
+    static constexpr int scr_words = (kTabWords + GW + K + SCR + 3) & ~3;
+    __device__ __host__ explicit StaticDims(const Dims &) {}
+};
+
+struct RuntimeDims {
+    int W, H, WH, K, GW, OW, F4, scr_words;
+    __device__ __host__ explicit RuntimeDims(const Dims &d)
+        : W(d.W), H(d.H), WH(d.WH), K(d.K), GW(d.GW), OW(d.OW), F4(d.F4), scr_words(d.scr_words) {}
+};
+
+inline int scr_words_for(int GW, int K, int OW) { return (kTabWords + GW + K + (OW > 624 ? OW : 624) + 3) & ~3; }
 
 struct State {
     uint32_t *head;      // [N][8]
@@ -86,6 +112,10 @@ __device__ __forceinline__ uint32_t pack_bullet(int x, int y, int dir, int owner
     return (uint32_t)x | ((uint32_t)y << 6) | ((uint32_t)dir << 12) | ((uint32_t)owner << 14);
 }
 
+// direction code (0 UP, 1 RIGHT, 2 DOWN, 3 LEFT) -> step, from 2-bit LUTs holding step + 1
+__device__ __forceinline__ int dir_dx(int dir) { return (int)((0x19u >> (2 * dir)) & 3u) - 1; }   // 0, +1, 0, -1
+__device__ __forceinline__ int dir_dy(int dir) { return (int)((0x64u >> (2 * dir)) & 3u) - 1; }   // -1, 0, +1, 0
+
 // ------------------------------------------------------------------ per-wave env context
 struct Player { int x, y, ammo, reload, alive; };
 
@@ -100,11 +130,21 @@ struct Env {
     uint32_t bw;         // lane i < nb: bullet i (canonical u16 packing)
 };
 
-__device__ __forceinline__ void load_env(const Dims &d, const State &s, int env, int lane, uint32_t *g, Env &e)
+template <class D>
+__device__ __forceinline__ void load_env(const D &d, const State &s, int env, int lane, uint32_t *g, Env &e)
 {
-    uint32_t hv = lane < kHeadWords ? s.head[(size_t)env * kHeadWords + lane] : 0u;
-    for (int w = lane; w < d.GW; w += kWave) g[w] = s.grid[(size_t)env * d.GW + w];
-    uint32_t bwv = lane < d.K ? (uint32_t)s.bullets[(size_t)env * d.K + lane] : 0u;
+    const uint32_t *hp = s.head + (size_t)env * kHeadWords;
+    const uint32_t *gp = s.grid + (size_t)env * d.GW;
+    const uint16_t *bp = s.bullets + (size_t)env * d.K;
+    // branch-free: every lane loads (clamped index), so no exec-mask juggling around the loads
+    const uint32_t hv = hp[lane & (kHeadWords - 1)];
+    const uint32_t bwv = (uint32_t)bp[min(lane, d.K - 1)];
+    if (d.GW <= kWave) {
+        const uint32_t gv = gp[min(lane, d.GW - 1)];
+        if (lane < d.GW) g[lane] = gv;
+    } else {
+        for (int w = lane; w < d.GW; w += kWave) g[w] = gp[w];
+    }
     uint32_t p1 = rdlane(hv, HD_P1), p2 = rdlane(hv, HD_P2), fl = rdlane(hv, HD_FLAGS);
     e.p[0] = { (int)(p1 & 255u), (int)((p1 >> 8) & 255u), (int)((p1 >> 16) & 255u), (int)(p1 >> 24), (int)(fl & FL_ALIVE1) != 0 };
     e.p[1] = { (int)(p2 & 255u), (int)((p2 >> 8) & 255u), (int)((p2 >> 16) & 255u), (int)(p2 >> 24), (int)(fl & FL_ALIVE2) != 0 };
@@ -120,8 +160,12 @@ __device__ __forceinline__ void load_env(const Dims &d, const State &s, int env,
     wave_sync();
 }
 
-__device__ __forceinline__ void store_env(const Dims &d, const State &s, int env, int lane, const uint32_t *g, const Env &e)
+template <class D>
+__device__ __forceinline__ void store_env(const D &d, const State &s, int env, int lane, const uint32_t *g, const Env &e)
 {
+    uint32_t *hp = s.head + (size_t)env * kHeadWords;
+    uint32_t *gp = s.grid + (size_t)env * d.GW;
+    uint16_t *bp = s.bullets + (size_t)env * d.K;
     uint64_t rb = (uint64_t)__double_as_longlong(e.ep_ret);
     uint32_t fl = (e.p[0].alive ? FL_ALIVE1 : 0u) | (e.p[1].alive ? FL_ALIVE2 : 0u) | (e.prev1 ? FL_PREV1 : 0u) |
                   (e.prev2 ? FL_PREV2 : 0u) | ((uint32_t)e.nb << 8);
@@ -129,13 +173,14 @@ __device__ __forceinline__ void store_env(const Dims &d, const State &s, int env
     uint32_t p2 = (uint32_t)e.p[1].x | ((uint32_t)e.p[1].y << 8) | ((uint32_t)e.p[1].ammo << 16) | ((uint32_t)e.p[1].reload << 24);
     uint32_t hv = lane == HD_P1 ? p1 : lane == HD_P2 ? p2 : lane == HD_FLAGS ? fl : lane == HD_STEP ? (uint32_t)e.step_count
                 : lane == HD_OPP ? e.opp_ctr : lane == HD_MTI ? (uint32_t)e.mti : lane == HD_RET_LO ? (uint32_t)rb : (uint32_t)(rb >> 32);
-    if (lane < kHeadWords) s.head[(size_t)env * kHeadWords + lane] = hv;
-    for (int w = lane; w < d.GW; w += kWave) s.grid[(size_t)env * d.GW + w] = g[w];
-    if (lane < d.K) s.bullets[(size_t)env * d.K + lane] = (uint16_t)(lane < e.nb ? e.bw : 0u);
+    if (lane < kHeadWords) hp[lane] = hv;
+    for (int w = lane; w < d.GW; w += kWave) gp[w] = g[w];
+    if (lane < d.K) bp[lane] = (uint16_t)(lane < e.nb ? e.bw : 0u);
 }
 
 // ------------------------------------------------------------------ actions (core.py:249-381, 510-525)
-__device__ __forceinline__ void emit_bullet(const Dims &d, int lane, Env &e, uint32_t word, bool valid, uint32_t &err)
+template <class D>
+__device__ __forceinline__ void emit_bullet(const D &d, int lane, Env &e, uint32_t word, bool valid, uint32_t &err)
 {
     if (!valid) return;
     if (e.nb >= d.K) { err |= ERR_BULLET_OVERFLOW; return; }
@@ -143,15 +188,15 @@ __device__ __forceinline__ void emit_bullet(const Dims &d, int lane, Env &e, uin
     e.nb += 1;
 }
 
-__device__ __forceinline__ void apply_action(const Dims &d, const uint32_t *g, int lane, int pid, int a, Env &e, uint32_t &err)
+template <class D>
+__device__ __forceinline__ void apply_action(const D &d, const uint32_t *g, int lane, int pid, int a, Env &e, uint32_t &err)
 {
     Player &p = e.p[pid];
     if (!p.alive || a == 0) return;
     const int type = (a + 3) >> 2, dir = (a - 1) & 3;          // env_wrappers.py:24-37
-    const int dx = (dir == 1) - (dir == 3), dy = (dir == 2) - (dir == 0);
     if (type == 1) {                                           // MOVE, core.py:249-296
-        const int nx = p.x + dx, ny = p.y + dy;
-        if (nx >= 0 && nx < d.W && ny >= 0 && ny < d.H) {
+        const int nx = p.x + dir_dx(dir), ny = p.y + dir_dy(dir);
+        if ((unsigned)nx < (unsigned)d.W && (unsigned)ny < (unsigned)d.H) {
             // walkable <=> tile != player's colour; P1 is BLACK (bit 0), P2 is WHITE (bit 1)
             if (rfl(tile_bit(g, ny * d.W + nx)) != (uint32_t)pid) { p.x = nx; p.y = ny; }
         }
@@ -184,12 +229,15 @@ __device__ __forceinline__ void reload(Player &p)               // core.py:383-3
 
 // ------------------------------------------------------------------ bullets (core.py:399-475)
 // Returns tile_diff = (#tiles turned WHITE) - (#tiles turned BLACK) of this update.
-__device__ __forceinline__ int update_bullets(const Dims &d, uint32_t *g, uint32_t *slots, int lane, Env &e)
+template <class D>
+__device__ __forceinline__ int update_bullets(const D &d, uint32_t *g, uint32_t *slots, int lane, Env &e)
 {
+    if (e.nb == 0) return 0;                                                       // wave-uniform shortcut
     const int bx = (int)(e.bw & 63u), by = (int)((e.bw >> 6) & 63u), dir = (int)((e.bw >> 12) & 3u), own = (int)((e.bw >> 14) & 1u);
-    const int nx = bx + (dir == 1) - (dir == 3), ny = by + (dir == 2) - (dir == 0);
-    const bool live = lane < e.nb && nx >= 0 && nx < d.W && ny >= 0 && ny < d.H;   // :428-431
+    const int nx = bx + dir_dx(dir), ny = by + dir_dy(dir);
+    const bool live = lane < e.nb && (unsigned)nx < (unsigned)d.W && (unsigned)ny < (unsigned)d.H;   // :428-431
     const int pos = live ? ny * d.W + nx : -1;
+    const int key = live ? (pos | (own << 16)) : -1;                               // tile + owner in one compare
 
     // Tile groups: a bullet meeting a different owner's bullet on its target tile vanishes
     // (:444-449); among same-owner arrivals only the first in list order survives (:453).
@@ -198,11 +246,9 @@ __device__ __forceinline__ int update_bullets(const Dims &d, uint32_t *g, uint32
     while (m) {
         const int j = __ffsll((unsigned long long)m) - 1;
         m &= m - 1;
-        const int pj = (int)rdlane((uint32_t)pos, j);
-        const int oj = (int)rdlane((uint32_t)own, j);
-        const bool same = pos == pj;
-        cancel |= same && own != oj;
-        dup |= same && own == oj && j < lane;
+        const int kj = (int)rdlane((uint32_t)key, j);
+        cancel |= (key ^ kj) == 0x10000;                                           // same tile, other owner
+        dup |= key == kj && j < lane;                                              // same tile, same owner, earlier in the list
     }
     const bool keep = live && !cancel && !dup;
 
@@ -217,9 +263,9 @@ __device__ __forceinline__ int update_bullets(const Dims &d, uint32_t *g, uint32
     const int tile_diff = __popcll(__ballot(f1)) - __popcll(__ballot(f2));
 
     // kills (:464-470): a surviving bullet on an alive non-owner's tile
-    const int pos1 = e.p[0].y * d.W + e.p[0].x, pos2 = e.p[1].y * d.W + e.p[1].x;
-    if (e.p[0].alive && __ballot(keep && own == 1 && pos == pos1) != 0ull) e.p[0].alive = 0;
-    if (e.p[1].alive && __ballot(keep && own == 0 && pos == pos2) != 0ull) e.p[1].alive = 0;
+    const int key1 = (e.p[0].y * d.W + e.p[0].x) | 0x10000, key2 = e.p[1].y * d.W + e.p[1].x;
+    if (e.p[0].alive && __ballot(keep && key == key1) != 0ull) e.p[0].alive = 0;  // P2's bullet on P1's tile
+    if (e.p[1].alive && __ballot(keep && key == key2) != 0ull) e.p[1].alive = 0;  // P1's bullet on P2's tile
 
     // stable compaction: survivors keep list order == first-arrival order of their tiles (:473)
     const uint64_t km = __ballot(keep);
@@ -245,7 +291,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
 // index order; inside a pass every lane reads before any lane writes, which reproduces the
 // sequential recurrence exactly: word k needs OLD k, OLD k+1 (NEW word 0 for k = 623) and
 // word k+397 (OLD for k < 227, else NEW word k-227, written >= 3 passes earlier).
-__device__ inline void mt_twist(uint32_t *mtg, uint32_t *scr, int lane)
+__device__ __attribute__((noinline)) void mt_twist(uint32_t *mtg, uint32_t *scr, int lane)
 {
     for (int i = lane; i < 624; i += kWave) scr[i] = mtg[i];
     wave_sync();
@@ -269,7 +315,8 @@ __device__ inline void mt_twist(uint32_t *mtg, uint32_t *scr, int lane)
 
 // InversusEnv.reset() (core.py:55-154) + SingleInversusRLEnv.reset() bookkeeping
 // (env_wrappers.py:278-283).  scr: >= 624 LDS words.
-__device__ inline void reset_env(const Dims &d, const State &s, int env, int lane, uint32_t *g, uint32_t *scr, Env &e)
+template <class D>
+__device__ inline void reset_env(const D &d, const State &s, int env, int lane, uint32_t *g, uint32_t *scr, Env &e)
 {
     uint32_t *mtg = s.mt + (size_t)env * kMtStride;
     const uint32_t nx = (uint32_t)(d.W - 2), ny = (uint32_t)(d.H - 2);
@@ -316,7 +363,7 @@ __device__ inline void reset_env(const Dims &d, const State &s, int env, int lan
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 const int x = cx[c] + (q == 1) - (q == 2), yy = cy[c] + (q == 3) - (q == 4);
-                if (x >= 0 && x < d.W && yy >= 0 && yy < d.H) {
+                if ((unsigned)x < (unsigned)d.W && (unsigned)yy < (unsigned)d.H) {
                     const int pos = yy * d.W + x;
                     if ((pos >> 5) == w) {
                         if (c < 2) word |= 1u << (pos & 31); else clr |= 1u << (pos & 31);
@@ -381,46 +428,47 @@ __device__ __forceinline__ uint32_t apply_perm4(uint32_t list, uint32_t perm)
     return t;
 }
 
-__device__ inline int dummy_action(const Dims &d, const uint32_t *g, const Env &e, int hard, uint32_t seed, uint32_t genv, uint32_t ctr)
+// The draws: word block 0 = {u0, u1, u2, swap}, block 1 = shuffle A, block 2 = shuffle B; u = word * 2^-32
+// is only ever compared with a constant, so the compares are done on the integer word:
+//   u < 0.2   <=> word <= 858993459      u < 0.05 <=> word <= 214748364      u > 0.001 <=> word >= 4294968
+// (0.2 * 2^32 = 858993459.2, 0.05 * 2^32 = 214748364.8, 0.001 * 2^32 = 4294967.296).
+// Blocks 1 and 2 are generated only on the branches that consume them.
+template <class D>
+__device__ inline int dummy_action(const D &d, const uint32_t *g, const Env &e, int hard, uint32_t seed, uint32_t genv, uint32_t ctr)
 {
     const Player &p1 = e.p[0], &p2 = e.p[1];
     if (!p2.alive) return 0;                                               // :77-78
     const U4 x = philox4x32(ctr, genv, 0u, kTagDummy, seed, kKey1);
-    const U4 y = philox4x32(ctr, genv, 1u, kTagDummy, seed, kKey1);
-    const U4 z = philox4x32(ctr, genv, 2u, kTagDummy, seed, kKey1);
-    const double u0 = (double)x.x * (1.0 / 4294967296.0), u1 = (double)x.y * (1.0 / 4294967296.0),
-                 u2 = (double)x.z * (1.0 / 4294967296.0);
-    const double shoot_prob = hard ? 0.2 : 0.0, random_move_prob = hard ? 0.05 : 0.0, move_prob = 0.001;   // :81-89
+
+    const bool x_al = p2.x == p1.x, y_al = p2.y == p1.y;
+    if (hard && x.x <= 858993459u && p2.ammo > 0 && (x_al || y_al)) {     // :96-101, shoot_prob 0.2 (0 when easy)
+        if (x_al) return 5 + (p1.y < p2.y ? 0 : 2);
+        return 5 + (p1.x < p2.x ? 3 : 1);
+    }
+    if (!hard && x.z >= 4294968u) return 0;                                // :122-124 (easy: random_move_prob is 0)
 
     // walkable-for-P2 mask over directions (in bounds and tile != WHITE), :116-118 etc.
     uint32_t walk = 0u;
 #pragma unroll
     for (int dir = 0; dir < 4; ++dir) {
-        const int nx = p2.x + (dir == 1) - (dir == 3), ny = p2.y + (dir == 2) - (dir == 0);
-        if (nx >= 0 && nx < d.W && ny >= 0 && ny < d.H && rfl(tile_bit(g, ny * d.W + nx)) == 0u) walk |= 1u << dir;
-    }
-
-    const bool x_al = p2.x == p1.x, y_al = p2.y == p1.y;
-    if (u0 < shoot_prob && p2.ammo > 0 && (x_al || y_al)) {                 // :96-101
-        if (x_al) return 5 + (p1.y < p2.y ? 0 : 2);
-        return 5 + (p1.x < p2.x ? 3 : 1);
+        const int nx = p2.x + dir_dx(dir), ny = p2.y + dir_dy(dir);
+        if ((unsigned)nx < (unsigned)d.W && (unsigned)ny < (unsigned)d.H && rfl(tile_bit(g, ny * d.W + nx)) == 0u) walk |= 1u << dir;
     }
     uint32_t dirs = 0u | (2u << 4) | (3u << 8) | (1u << 12);               // [UP, DOWN, LEFT, RIGHT], :104
-    if (u1 < random_move_prob) {                                           // :105-119
-        dirs = apply_perm4(dirs, fy_perm4(x.w, y.x, y.y));
+    if (hard && x.y <= 214748364u) {                                       // :105-119, random_move_prob 0.05
+        const U4 y = philox4x32(ctr, genv, 1u, kTagDummy, seed, kKey1);
+        dirs = apply_perm4(dirs, fy_perm4(y.x, y.y, y.z));
         const int c = (int)(dirs & 15u);
         if ((walk >> c) & 1u) return 1 + c;
-    }
-    if (!hard) {                                                           // :122-124
-        if (u2 > move_prob) return 0;
     }
     const int dx = p1.x - p2.x, dy = p1.y - p2.y;                          // :127-138
     int c0 = -1, c1 = -1;
     if (dx != 0) c0 = dx > 0 ? 1 : 3;
     if (dy != 0) { const int c = dy > 0 ? 2 : 0; if (c0 < 0) c0 = c; else c1 = c; }
-    if (c1 >= 0 && __umulhi(y.z, 2u) == 0u) { const int t = c0; c0 = c1; c1 = t; }
+    if (c1 >= 0 && __umulhi(x.w, 2u) == 0u) { const int t = c0; c0 = c1; c1 = t; }
     if (c0 >= 0 && ((walk >> c0) & 1u)) return 1 + c0;                     // :140-152
     if (c1 >= 0 && ((walk >> c1) & 1u)) return 1 + c1;
+    const U4 z = philox4x32(ctr, genv, 2u, kTagDummy, seed, kKey1);
     dirs = apply_perm4(dirs, fy_perm4(z.x, z.y, z.z));                      // :155-168
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -447,13 +495,20 @@ __device__ __forceinline__ uint32_t grid_window(const uint32_t *g, int GW, uint3
     return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
 }
 
+// The wave's nibble -> float4 table (16 entries x 16 B in LDS): entry n = (bit0, bit1, bit2, bit3) of n as 0.0f / 1.0f.
+__device__ __forceinline__ void init_nibble_table(float *tab, int lane)
+{
+    tab[lane] = ((lane >> 2) >> (lane & 3)) & 1 ? 1.0f : 0.0f;
+}
+
 // Render player `pid`'s 12-channel observation of the current state.  The 12*W*H floats are
 // 0/1, so the wave first assembles them as ONE packed bitstring in LDS (channels 0/1 by a
 // funnel-shifted copy of the grid words, channels 2..11 by per-lane LDS OR of single bits),
 // then every lane expands nibbles to float4 and streams them out: consecutive lanes write
 // consecutive 16 B, 1 KiB per wave store instruction.
-__device__ inline void render_obs(const Dims &d, const uint32_t *g, uint32_t *ob, int lane, int pid, const Env &e,
-                                  float *__restrict__ obs_env, float *__restrict__ extra_env)
+template <class D>
+__device__ inline void render_obs(const D &d, const uint32_t *g, uint32_t *ob, const float4 *tab, int lane, int pid,
+                                  const Env &e, float *__restrict__ obs_env, float *__restrict__ extra_env)
 {
     const int WH = d.WH;
     const uint32_t lastmask = (WH & 31) ? ((1u << (WH & 31)) - 1u) : 0xffffffffu;
@@ -476,16 +531,13 @@ __device__ inline void render_obs(const Dims &d, const uint32_t *g, uint32_t *ob
         }
     }
     wave_sync();
+    // expand: float4 j of the observation = bits 4j..4j+3 of the bitstring, i.e. nibble (j & 7) of word
+    // j >> 3, looked up in the wave's 16-entry float4 table (one conflict-free ds_read_b128, no VALU
+    // selects); lanes 8q..8q+7 share a word and the nibble position of a lane never changes.
     float4 *dst = reinterpret_cast<float4 *>(obs_env);
-    for (int j = lane; j < d.F4; j += kWave) {
-        const uint32_t nib = ob[j >> 3] >> ((j & 7) * 4);
-        float4 v;
-        v.x = (nib & 1u) ? 1.0f : 0.0f;
-        v.y = (nib & 2u) ? 1.0f : 0.0f;
-        v.z = (nib & 4u) ? 1.0f : 0.0f;
-        v.w = (nib & 8u) ? 1.0f : 0.0f;
-        dst[j] = v;
-    }
+    const uint32_t sh = (uint32_t)(lane & 7) * 4u;
+#pragma unroll 4
+    for (int j = lane; j < d.F4; j += kWave) dst[j] = tab[(ob[j >> 3] >> sh) & 15u];
     if (extra_env && lane < 4) {                                            // :238-243: f32(ammo / 6) computed in f64
         const Player &q = (lane & 1) ? en : me;
         float val;

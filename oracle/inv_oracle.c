@@ -489,12 +489,13 @@ int orc_dummy_device(orc_env *e, int hard, uint32_t seed, uint32_t global_env)
     orc_philox4x32(ctr, global_env, 1u, ORC_TAG_DUMMY, seed, ORC_KEY1, y);
     orc_philox4x32(ctr, global_env, 2u, ORC_TAG_DUMMY, seed, ORC_KEY1, z);
     double u[3] = { x[0] * (1.0 / 4294967296.0), x[1] * (1.0 / 4294967296.0), x[2] * (1.0 / 4294967296.0) };
-    uint32_t wa[3] = { x[3], y[0], y[1] };
+    /* block 0 = {u0, u1, u2, swap word}, block 1 = shuffle A words, block 2 = shuffle B words */
+    uint32_t wa[3] = { y[0], y[1], y[2] };
     uint32_t wb[3] = { z[0], z[1], z[2] };
     int perm_a[4], perm_b[4];
     fy_perm4(wa, perm_a);
     fy_perm4(wb, perm_b);
-    int swap_c = mulhi32(y[2], 2u) == 0u;   /* n=2 shuffle: i=1, j=randbelow(2), swap iff j==0 */
+    int swap_c = mulhi32(x[3], 2u) == 0u;   /* n=2 shuffle: i=1, j=randbelow(2), swap iff j==0 */
     return orc_dummy_decide(e, hard, u, perm_a, swap_c, perm_b);
 }
 
