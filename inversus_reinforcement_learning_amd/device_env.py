@@ -145,6 +145,22 @@ class DeviceEnvBatch:
         L.raise_for(rc, self.lib)
         return r
 
+    def make_stepper(self, out, a2=None, auto_reset=True, flags=L.INV_STEP_DEFAULT):
+        """Pre-marshalled inv_step: returns step(a1_device_address) costing one ctypes call.  For
+        launch-rate-sensitive loops (the per-step Python marshalling of step() is ~20 us)."""
+        co = self._c_out(out)
+        a2t = self._as_actions(a2)
+        fl = int(flags) | (L.INV_STEP_AUTO_RESET if auto_reset else 0)
+        fn, h, ref, a2p, st = self.lib.inv_step, self.h, C.byref(co), _ptr(a2t), _stream()
+        lib = self.lib
+
+        def step(a1_ptr):
+            rc = fn(h, a1_ptr, a2p, fl, ref, st)
+            if rc:
+                L.raise_for(rc, lib)
+        step.keepalive = (co, out, a2t)
+        return step
+
     def rollout(self, a1, a2=None, obs=True, obs_p2=False, reward64=False, out=None):
         """T vector steps in one launch with pre-supplied actions a1[T, N] (always auto-resets)."""
         T = int(a1.shape[0])

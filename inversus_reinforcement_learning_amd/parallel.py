@@ -1,0 +1,91 @@
+"""Multi-GPU plumbing: one process per GPU, env shards by global index, and the only collectives
+of the training loop (policy-gradient all-reduce, advantage-normalisation statistics).
+
+The env path itself needs no collective: rank r owns global envs [r*n, (r+1)*n) and all RNG
+streams are keyed by the global index.  Backend "nccl" is RCCL on
+ROCm (xGMI between the 8 GPUs of a node); the same code runs on "gloo" for the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or dist.is_initialized():
+        return world()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr)
+        dist.init_process_group(backend, device_id=torch.device("cuda", lr))
+    else:
+        dist.init_process_group(backend)
+    return world()
+
+
+def shard_range(total_envs, rank=None, world_size=None):
+    """Contiguous global env range of a rank: (offset, count); remainder spread over the first ranks."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    base, rem = divmod(int(total_envs), int(world_size))
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+class FlatGradReducer:
+    """Averages gradients over ranks with ONE all-reduce of a flat f32 bucket per optimizer step
+    (10 249 582 params = 41 MB at 15x10: over xGMI a ring moves 2*(G-1)/G*41 MB per GPU).  The
+    bucket is a persistent buffer whose slices are the parameters' .grad tensors, so there is no
+    pack / unpack copy."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def reduce(self):
+        _, w = world()
+        if w > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(w)
+
+
+def global_mean_std(x):
+    """Mean and population std of x over ALL ranks (advantage normalisation, ppo_agent.py:173):
+    one all-reduce of (sum, sum of squares, count) in f64."""
+    s = torch.stack([x.double().sum(), (x.double() ** 2).sum(),
+                     torch.tensor(float(x.numel()), dtype=torch.float64, device=x.device)])
+    _, w = world()
+    if w > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    mean = s[0] / s[2]
+    var = (s[1] / s[2] - mean * mean).clamp_min(0.0)
+    return mean.to(x.dtype), var.sqrt().to(x.dtype)
+
+
+def broadcast_parameters(module, src=0):
+    _, w = world()
+    if w > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src)

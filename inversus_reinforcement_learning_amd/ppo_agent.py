@@ -1,0 +1,158 @@
+"""PPO agent with the reference's interface (inversus_rl/ppo_agent.py:13-249), device resident.
+
+Same constructor arguments and defaults, `act / store_step / reset_buffers / compute_advantages /
+update` with the same meaning.  What changes is where things live: observations arrive as device
+tensors written by the HIP kernels, the rollout buffer is a list of [N,...] device tensors (one
+entry per vector step, i.e. the reference's env-minor order k = t*N + i), GAE runs in the HIP
+scan kernel (csrc/inv_gae.hip) and the minibatch loop never leaves the GPU.
+
+GAE layout:
+  * "reference_flat" reproduces the reference bit for bit: ONE chain over the env-interleaved
+    buffer, so for num_envs > 1 V[k+1] is the next env at the same timestep.
+  * "per_env" (default) scans each env's own trajectory -- the reference's own num_envs == 1
+    behaviour applied per env.  It is what multi-GPU sharding needs (no cross-env coupling).
+Deviations from the reference that cannot be bit-matched in parallel (global-RNG consumers):
+Categorical sampling and the minibatch permutation use torch's device generator.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import parallel
+from .device_env import gae as device_gae
+
+
+class PPOAgent:
+    def __init__(self, policy, lr=1e-4, gamma=0.99, lam=0.95, clip_ratio=0.2, epochs=4, batch_size=512,
+                 entropy_coef=0.02, value_coef=0.1, device="cuda", *, gae_layout="per_env", max_grad_norm=0.5):
+        self.device = torch.device(device)
+        self.policy = policy.to(self.device)
+        self.gamma, self.lam, self.clip_ratio = gamma, lam, clip_ratio
+        self.epochs, self.batch_size = epochs, batch_size
+        self.entropy_coef, self.value_coef = entropy_coef, value_coef
+        self.gae_layout, self.max_grad_norm = gae_layout, max_grad_norm
+        self.optimizer = optim.Adam(self.policy.parameters(), lr=lr)
+        _, w = parallel.world()
+        self.reducer = parallel.FlatGradReducer(self.policy.parameters()) if w > 1 else None
+        self.reset_buffers()
+
+    # ------------------------------------------------------------------ buffers (ppo_agent.py:58-66, 108-125)
+    def reset_buffers(self):
+        self.obs_grid_buffer, self.obs_extra_buffer = [], []
+        self.action_buffer, self.log_prob_buffer = [], []
+        self.reward_buffer, self.value_buffer, self.done_buffer = [], [], []
+
+    def _t(self, x, dtype):
+        return torch.as_tensor(x, dtype=dtype, device=self.device)
+
+    def store_step(self, grid_tensor, extra_vector, action, log_prob, value, reward, done):
+        """One transition (the reference's per-env call) -- kept for API compatibility."""
+        self.store_batch(self._t(grid_tensor, torch.float32)[None], self._t(extra_vector, torch.float32)[None],
+                         self._t([action], torch.int64), self._t([log_prob], torch.float32),
+                         self._t([value], torch.float32), self._t([reward], torch.float32), self._t([done], torch.bool))
+
+    def store_batch(self, grid, extra, actions, log_probs, values, rewards, dones):
+        """One vector step: [N,...] tensors, appended in env order (== the reference's fill order)."""
+        self.obs_grid_buffer.append(self._t(grid, torch.float32))
+        self.obs_extra_buffer.append(self._t(extra, torch.float32))
+        self.action_buffer.append(self._t(actions, torch.int64))
+        self.log_prob_buffer.append(self._t(log_probs, torch.float32))
+        self.value_buffer.append(self._t(values, torch.float32))
+        self.reward_buffer.append(self._t(rewards, torch.float32))
+        self.done_buffer.append(self._t(dones, torch.bool))
+
+    # ------------------------------------------------------------------ act (ppo_agent.py:68-106)
+    @torch.no_grad()
+    def act(self, grid_tensors, extra_vectors):
+        """Sample actions.  NumPy in -> NumPy out (reference contract); device tensors in -> device
+        tensors out (actions int64, log_probs f32, values f32)."""
+        as_numpy = not isinstance(grid_tensors, torch.Tensor)
+        self.policy.eval()
+        logits, values = self.policy(self._t(grid_tensors, torch.float32), self._t(extra_vectors, torch.float32))
+        dist = torch.distributions.Categorical(logits=logits)
+        actions = dist.sample()
+        log_probs = dist.log_prob(actions)
+        values = values.squeeze(-1)
+        if as_numpy:
+            return actions.cpu().numpy(), log_probs.cpu().numpy(), values.cpu().numpy()
+        return actions, log_probs, values
+
+    # ------------------------------------------------------------------ GAE (ppo_agent.py:127-157)
+    def _stacked(self):
+        r = torch.stack([x.reshape(-1) for x in self.reward_buffer])      # [T, N]
+        v = torch.stack([x.reshape(-1) for x in self.value_buffer])
+        d = torch.stack([x.reshape(-1) for x in self.done_buffer])
+        return r, v, d
+
+    def _advantages_device(self, last_value=0.0):
+        r, v, d = self._stacked()
+        if self.device.type != "cuda":
+            raise RuntimeError("GAE runs in the HIP kernel; the agent must live on the GPU")
+        lv = last_value
+        if self.gae_layout == "per_env" and not torch.is_tensor(lv):
+            lv = torch.full((r.shape[1],), float(lv), dtype=torch.float32, device=self.device)
+        adv, ret = device_gae(r, v, d, self.gamma, self.lam, lv, layout=self.gae_layout)
+        return adv.reshape(-1), ret.reshape(-1)
+
+    def compute_advantages(self, last_value=0.0):
+        """-> (advantages, returns) as flat NumPy f32 arrays in buffer order, like the reference."""
+        adv, ret = self._advantages_device(last_value)
+        return adv.cpu().numpy(), ret.cpu().numpy()
+
+    # ------------------------------------------------------------------ update (ppo_agent.py:159-247)
+    def update(self, advantages=None, returns=None):
+        """PPO update over the stored rollout.  `advantages` / `returns` (flat, buffer order) may be
+        supplied by the caller; by default they come from the HIP GAE kernel."""
+        if len(self.obs_grid_buffer) == 0:
+            return {}
+        if advantages is None:
+            advantages, returns = self._advantages_device()
+        else:
+            advantages, returns = self._t(advantages, torch.float32).reshape(-1), self._t(returns, torch.float32).reshape(-1)
+        mean, std = parallel.global_mean_std(advantages)                  # population std, all ranks (:173)
+        advantages = (advantages - mean) / (std + 1e-8)
+
+        obs_grid = torch.cat(self.obs_grid_buffer)
+        obs_extra = torch.cat(self.obs_extra_buffer)
+        actions = torch.cat(self.action_buffer)
+        old_log_probs = torch.cat(self.log_prob_buffer)
+
+        self.policy.train()
+        tot_p = torch.zeros((), device=self.device)
+        tot_v = torch.zeros((), device=self.device)
+        tot_e = torch.zeros((), device=self.device)
+        num_samples = obs_grid.shape[0]
+        num_updates = 0
+        params = [p for p in self.policy.parameters() if p.requires_grad]
+        for _ in range(self.epochs):
+            indices = torch.randperm(num_samples, device=self.device)
+            for start in range(0, num_samples, self.batch_size):
+                idx = indices[start:start + self.batch_size]
+                logits, values = self.policy(obs_grid[idx], obs_extra[idx])
+                dist = torch.distributions.Categorical(logits=logits)
+                new_log_probs = dist.log_prob(actions[idx])
+                entropy = dist.entropy().mean()
+                ratio = torch.exp(new_log_probs - old_log_probs[idx])
+                adv = advantages[idx]
+                surr1 = ratio * adv
+                surr2 = torch.clamp(ratio, 1.0 - self.clip_ratio, 1.0 + self.clip_ratio) * adv
+                policy_loss = -torch.min(surr1, surr2).mean()
+                value_loss = nn.functional.mse_loss(values.squeeze(-1), returns[idx])
+                loss = policy_loss + self.value_coef * value_loss - self.entropy_coef * entropy
+                if self.reducer is not None:
+                    self.reducer.zero()                                   # grads accumulate into the flat bucket
+                    loss.backward()
+                    self.reducer.reduce()                                 # ONE RCCL all-reduce per optimizer step
+                else:
+                    self.optimizer.zero_grad()
+                    loss.backward()
+                torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                self.optimizer.step()
+                tot_p += policy_loss.detach()
+                tot_v += value_loss.detach()
+                tot_e += entropy.detach()
+                num_updates += 1
+        self.reset_buffers()
+        return {"policy_loss": float(tot_p) / num_updates, "value_loss": float(tot_v) / num_updates,
+                "entropy": float(tot_e) / num_updates}

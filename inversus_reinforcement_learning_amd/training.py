@@ -1,0 +1,166 @@
+"""Rollout collection + PPO loops of the reference (inversus_rl/training.py:53-201, 204-375) with
+every tensor resident on the GPU: act -> step (HIP, auto-reset fused) -> store, then update.
+
+    train_vs_dummy(num_envs, total_steps, log_dir, opponent_difficulty, load_model)
+    train_selfplay(num_envs, total_steps, log_dir, load_model)
+
+keep the reference's signatures, `steps_per_env = max(2048 // num_envs, 128)`, the terminal
+transition stored before the reset, the 20 000-step self-play opponent refresh, the CSV columns
+and the plain `state_dict` checkpoints (so the reference's play.py / visualize_training.py read
+them).  Multi-GPU: launch with torchrun; each rank owns a contiguous env shard, gradients are
+averaged with one RCCL all-reduce per optimizer step (parallel.py).
+"""
+import csv
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import parallel
+from .device_env import DeviceEnvBatch
+from .policies import InversusCNNPolicy
+from .ppo_agent import PPOAgent
+
+CSV_COLUMNS = ["step", "episode", "avg_reward", "win_rate", "avg_ep_len", "policy_loss", "value_loss", "entropy"]
+
+
+class TrainingLogger:
+    """training_log.csv with the reference's 8 columns (training.py:16-50)."""
+
+    def __init__(self, log_dir):
+        self.log_dir = log_dir
+        os.makedirs(log_dir, exist_ok=True)
+        self.csv_path = os.path.join(log_dir, "training_log.csv")
+        with open(self.csv_path, "w", newline="") as f:
+            csv.writer(f).writerow(CSV_COLUMNS)
+
+    def log(self, **row):
+        with open(self.csv_path, "a", newline="") as f:
+            csv.writer(f).writerow([row[c] for c in CSV_COLUMNS])
+
+
+class RolloutCollector:
+    """T vector steps of N envs without leaving the device.
+
+    vs_dummy : a1 = policy sample, a2 = device dummy opponent (inside the step kernel).
+    selfplay : one step kernel emits the P1 AND P2 observations of the new state; the next step's
+               a1 / a2 come from one batched forward of `policy` / `opponent` each (the reference
+               does N batch-of-1 forwards, training.py:249-258)."""
+
+    def __init__(self, batch, agent, opponent=None):
+        self.batch, self.agent, self.opponent = batch, agent, opponent
+        self.selfplay = batch.opponent == "selfplay"
+        if self.selfplay and opponent is None:
+            raise ValueError("opponent_policy required for selfplay mode")
+        self.out = batch._alloc_out((), True, self.selfplay, False, None)
+        self.obs = batch.render(0)
+        self.obs_p2 = batch.render(1) if self.selfplay else None
+        self.episodes = {"return": [], "length": [], "win": []}
+
+    @torch.no_grad()
+    def _opponent_actions(self):
+        self.opponent.eval()
+        logits, _ = self.opponent(self.obs_p2[0], self.obs_p2[1])
+        return torch.distributions.Categorical(logits=logits).sample().to(torch.uint8)
+
+    def collect(self, steps):
+        b, agent = self.batch, self.agent
+        for _ in range(steps):
+            grid, extra = self.obs
+            actions, log_probs, values = agent.act(grid, extra)
+            a2 = self._opponent_actions() if self.selfplay else None
+            # fresh obs buffers per step: the rollout buffer keeps references to them (ppo_agent.py:119)
+            out = b._alloc_out((), True, self.selfplay, False, None)
+            r = b.step(actions.to(torch.uint8), a2, auto_reset=True, out=out)
+            agent.store_batch(grid, extra, actions, log_probs, values, r.reward, r.done)
+            self.obs = (r.obs, r.extra)
+            if self.selfplay:
+                self.obs_p2 = (r.obs_p2, r.extra_p2)
+            self._track(r)
+        return steps * b.num_envs
+
+    def _track(self, r):
+        done = r.done.bool()
+        if bool(done.any()):                                  # one small D2H per step, like the reference's info dicts
+            idx = done.nonzero().flatten()
+            self.episodes["return"] += r.episode_return[idx].tolist()
+            self.episodes["length"] += r.episode_steps[idx].tolist()
+            self.episodes["win"] += ((r.info_flags[idx] & L.INV_INFO_WIN) != 0).int().tolist()
+
+
+def _make(num_envs_total, opponent_type, difficulty, seed, width, height):
+    rank, world_size = parallel.init_from_env()
+    offset, count = parallel.shard_range(num_envs_total, rank, world_size)
+    base = int.from_bytes(os.urandom(7), "little") if seed is None else int(seed)
+    if world_size > 1 and seed is None:
+        t = torch.tensor([base], dtype=torch.int64, device="cuda")
+        torch.distributed.broadcast(t, 0)
+        base = int(t.item())
+    batch = DeviceEnvBatch(count, width, height, opponent=opponent_type, difficulty=difficulty,
+                           opp_seed=base, env_offset=offset)
+    batch.seed(base + offset + np.arange(count, dtype=np.int64))    # seed + global env index (env_wrappers.py:463)
+    batch.reset()                                                   # constructor reset (core.py:53)
+    batch.reset()                                                   # env_runner.reset() (training.py:99)
+    policy = InversusCNNPolicy(12, height, width, 4)
+    return rank, world_size, batch, policy
+
+
+def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, width, height, agent_kwargs, verbose):
+    rank, world_size, batch, policy = _make(num_envs, "dummy" if mode == "vs_dummy" else "selfplay", difficulty,
+                                            seed, width, height)
+    if load_model:
+        policy.load_state_dict(torch.load(load_model, map_location="cpu", weights_only=True))
+    policy = policy.cuda()
+    parallel.broadcast_parameters(policy)
+    opponent = None
+    if mode == "selfplay":
+        opponent = InversusCNNPolicy(12, height, width, 4).cuda()
+        opponent.load_state_dict(policy.state_dict())               # initial opponent is a clone (training.py:239)
+        opponent.eval()
+    agent = PPOAgent(policy, **(agent_kwargs or {}))
+    collector = RolloutCollector(batch, agent, opponent)
+    logger = TrainingLogger(log_dir) if (log_dir and rank == 0) else None
+
+    steps_per_env = max(2048 // num_envs, 128)                      # training.py:105-107
+    step_count, episode_count, last_log, last_refresh = 0, 0, 0, 0
+    stats, t0 = {}, time.time()
+    while step_count < total_steps:
+        todo = min(steps_per_env, -(-(total_steps - step_count) // num_envs))
+        collector.collect(todo)
+        step_count += todo * num_envs
+        stats = agent.update()
+        if mode == "selfplay" and step_count - last_refresh >= 20000:   # training.py:265,331-334
+            opponent.load_state_dict(policy.state_dict())
+            last_refresh = step_count
+        ep = collector.episodes
+        episode_count = len(ep["return"]) * world_size
+        if ep["return"] and (step_count - last_log >= 1000 or step_count >= total_steps):
+            last_log = step_count
+            row = dict(step=step_count, episode=episode_count, avg_reward=float(np.mean(ep["return"][-100:])),
+                       win_rate=float(np.mean(ep["win"][-100:])), avg_ep_len=float(np.mean(ep["length"][-100:])),
+                       policy_loss=stats.get("policy_loss", 0.0), value_loss=stats.get("value_loss", 0.0),
+                       entropy=stats.get("entropy", 0.0))
+            if logger:
+                logger.log(**row)
+            if verbose and rank == 0:
+                print(f"Step {step_count}/{total_steps} | Episodes: {episode_count} | Avg Reward: {row['avg_reward']:.3f} | "
+                      f"Win Rate: {row['win_rate']:.3f} | Avg Ep Len: {row['avg_ep_len']:.1f} | Time: {time.time() - t0:.1f}s")
+        if log_dir and rank == 0 and step_count % 50000 == 0:
+            torch.save(policy.state_dict(), os.path.join(log_dir, f"policy_checkpoint_{step_count}.pt"))
+    batch.check()
+    if log_dir and rank == 0:
+        torch.save(policy.state_dict(), os.path.join(log_dir, "policy_final.pt"))
+    return {"steps": step_count, "episodes": episode_count, "seconds": time.time() - t0, **stats}
+
+
+def train_vs_dummy(num_envs=1, total_steps=500_000, log_dir="runs/inversus_vs_dummy", opponent_difficulty="easy",
+                   load_model=None, *, seed=None, width=15, height=10, agent_kwargs=None, verbose=True):
+    return _train("vs_dummy", num_envs, total_steps, log_dir, opponent_difficulty, load_model, seed, width, height,
+                  agent_kwargs, verbose)
+
+
+def train_selfplay(num_envs=1, total_steps=500_000, log_dir="runs/inversus_selfplay", load_model=None, *,
+                   seed=None, width=15, height=10, agent_kwargs=None, verbose=True):
+    return _train("selfplay", num_envs, total_steps, log_dir, "easy", load_model, seed, width, height, agent_kwargs, verbose)

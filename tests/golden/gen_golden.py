@@ -285,6 +285,30 @@ def gen_dummy(n_cases=3000):
     print("g6 dummy action histogram:", np.bincount(arr["action"], minlength=13))
 
 
+# --------------------------------------------------------------------------- G5
+def gen_policy():
+    """Reference policy graph under a fixed seed: outputs for 8 fixed observations, state_dict keys
+    and per-tensor sums (the 41 MB state_dict itself is not committed)."""
+    import torch
+    from inversus_rl.policies import InversusCNNPolicy
+    g3 = np.load(os.path.join(OUT, "g3_wrapper_15x10_uniform.npz"))
+    bits = g3["obs_next"][100, :8]                       # 8 mid-game observations
+    grid = np.unpackbits(bits, axis=1)[:, :1800].astype(np.float32).reshape(8, 12, 10, 15)
+    extra = g3["extra_next"][100, :8].astype(np.float32)
+    torch.manual_seed(0)
+    pol = InversusCNNPolicy(12, 10, 15, 4)
+    pol.eval()
+    with torch.no_grad():
+        logits, value = pol(torch.from_numpy(grid), torch.from_numpy(extra))
+    sd = pol.state_dict()
+    np.savez_compressed(os.path.join(OUT, "g5_policy.npz"), grid=grid, extra=extra,
+                        logits=logits.numpy(), value=value.numpy(),
+                        keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),
+                        sums=np.array([float(v.double().sum()) for v in sd.values()]),
+                        abs_sums=np.array([float(v.double().abs().sum()) for v in sd.values()]),
+                        n_params=sum(p.numel() for p in pol.parameters()))
+
+
 def main():
     gen_spawn(15, 10)
     gen_spawn(32, 32)
@@ -299,6 +323,7 @@ def main():
     gen_wrapper_trace("32x32_biased", 32, 32, 8, 256, base_seed=900, act_seed=203, biased=True, max_steps=100)
     gen_gae()
     gen_dummy()
+    gen_policy()
 
 
 if __name__ == "__main__":
