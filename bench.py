@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 NUM_ENVS = 16384            # per GPU (BASELINE.json metric: "env-steps/sec at 16384 envs")
 W, H, K = 15, 10, 16
+EV_GROUP = 10
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 
 
@@ -117,13 +118,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream around groups of EV_GROUP consecutive k_step launches (an event
+    # pair per launch costs ~2 us of queue markers per step); kernel_ms = group time / launches, so it
+    # includes the ~1.5 us dependent-launch boundary between steps of one env batch.
+    groups = [(k, min(k + EV_GROUP, args.steps)) for k in range(0, args.steps, EV_GROUP)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
     fence()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()                            # HIP events on the launch stream, around k_step
-        step(base + (args.warmup + k) * n)
-        ev[k][1].record()
+    for (lo, hi), (e0, e1) in zip(groups, ev):
+        e0.record()
+        for k in range(lo, hi):
+            step(base + (args.warmup + k) * n)
+        e1.record()
     fence()
     dt = time.perf_counter() - t0
     b.check()
