@@ -481,21 +481,31 @@ static void fy_perm4(const uint32_t w[3], int perm[4])
 #define ORC_TAG_ACTION 0x4143544eu   /* "ACTN" */
 #define ORC_KEY1       0x1234abcdu
 
+/* Draw words of the device dummy (see csrc/inv_device.h): key = lowbias32(genv * 0x9E3779B9 + seed),
+ * word(j) = lowbias32(key + (ctr * 16 + j) * 0x85EBCA6B); j = 0,1,2: u0,u1,u2; 3: candidate swap;
+ * 4..6: shuffle A; 8..10: shuffle B.  The oracle evaluates every word eagerly and feeds the pinned
+ * decision function; the kernel generates them lazily -- same values. */
+static uint32_t lowbias32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
 int orc_dummy_device(orc_env *e, int hard, uint32_t seed, uint32_t global_env)
 {
-    uint32_t x[4], y[4], z[4];
     uint32_t ctr = e->opp_ctr++;
-    orc_philox4x32(ctr, global_env, 0u, ORC_TAG_DUMMY, seed, ORC_KEY1, x);
-    orc_philox4x32(ctr, global_env, 1u, ORC_TAG_DUMMY, seed, ORC_KEY1, y);
-    orc_philox4x32(ctr, global_env, 2u, ORC_TAG_DUMMY, seed, ORC_KEY1, z);
-    double u[3] = { x[0] * (1.0 / 4294967296.0), x[1] * (1.0 / 4294967296.0), x[2] * (1.0 / 4294967296.0) };
-    /* block 0 = {u0, u1, u2, swap word}, block 1 = shuffle A words, block 2 = shuffle B words */
-    uint32_t wa[3] = { y[0], y[1], y[2] };
-    uint32_t wb[3] = { z[0], z[1], z[2] };
+    uint32_t key = lowbias32(global_env * 0x9E3779B9u + seed);
+    uint32_t w[11];
+    for (uint32_t j = 0; j < 11; j++) w[j] = lowbias32(key + (ctr * 16u + j) * 0x85EBCA6Bu);
+    double u[3] = { w[0] * (1.0 / 4294967296.0), w[1] * (1.0 / 4294967296.0), w[2] * (1.0 / 4294967296.0) };
+    uint32_t wa[3] = { w[4], w[5], w[6] };
+    uint32_t wb[3] = { w[8], w[9], w[10] };
     int perm_a[4], perm_b[4];
     fy_perm4(wa, perm_a);
     fy_perm4(wb, perm_b);
-    int swap_c = mulhi32(x[3], 2u) == 0u;   /* n=2 shuffle: i=1, j=randbelow(2), swap iff j==0 */
+    int swap_c = mulhi32(w[3], 2u) == 0u;   /* n=2 shuffle: i=1, j=randbelow(2), swap iff j==0 */
     return orc_dummy_decide(e, hard, u, perm_a, swap_c, perm_b);
 }
 

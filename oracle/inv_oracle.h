@@ -93,9 +93,9 @@ int  orc_wrapper_step(orc_env *e, int a1, int a2, double *reward, int *done, orc
 int orc_dummy_decide(const orc_env *e, int hard, const double u[3],
                      const int perm_a[4], int swap_c, const int perm_b[4]);
 
-/* The counter RNG the HIP kernels use for the on-device dummy opponent and for
- * synthetic action streams (Philox4x32-10).  Not in the reference (which uses the
- * process-global `random`), so parity with the reference is statistical. */
+/* The counter RNGs the HIP kernels use: a lowbias32 counter hash for the on-device dummy
+ * opponent's draws, Philox4x32-10 for synthetic action streams.  Not in the reference (which
+ * uses the process-global `random`), so parity with the reference is statistical. */
 void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                     uint32_t k0, uint32_t k1, uint32_t out[4]);
 int  orc_dummy_device(orc_env *e, int hard, uint32_t seed, uint32_t global_env); /* consumes e->opp_ctr */

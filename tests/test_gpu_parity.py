@@ -342,3 +342,58 @@ def test_full_size_properties(torch_cuda):
         assert np.array_equal(e.grid_bits(), s["grid"][i]) and np.array_equal(e.players(), s["players"][i]), i
         assert e.s.step_count == s["step_count"][i] and e.s.episode_return == s["episode_return"][i]
     b.check()
+
+
+# ------------------------------------------------------------------ ragged sizes, other K, overflow
+@pytest.mark.parametrize("n,W,H,K", [(1, 15, 10, 16), (3, 15, 10, 16), (5, 32, 32, 16), (7, 9, 4, 8), (130, 15, 10, 32),
+                                     (6, 64, 3, 64), (9, 3, 64, 16)])
+def test_ragged_batches_and_other_bullet_capacities(torch_cuda, n, W, H, K):
+    """N not a multiple of the 4 envs per block, K != 16, extreme aspect ratios (generic dims path)."""
+    from oracle import oracle as orc
+    rng = np.random.RandomState(n * 31 + W)
+    seeds = 77 + np.arange(n, dtype=np.int64)
+    b = make(n, W, H, max_bullets=K, opponent="selfplay", max_episode_steps=40)
+    b.seed(seeds); b.reset()
+    ob = orc.OracleBatch(n, W, H, max_episode_steps=40)
+    ob.seed_reset(seeds)
+    for t in range(80):
+        a = [np.where(rng.random_sample(n) < 0.6, rng.randint(5, 13, n), rng.randint(0, 13, n)).astype(np.uint8) for _ in range(2)]
+        r = b.step(a[0], a[1], auto_reset=True, obs_p2=True, reward64=True)
+        o_obs, o_extra, _, o_r64, o_done, o_info = ob.step(a[0], a[1])
+        _compare_step(b, ob, r, o_obs, o_extra, o_r64, o_done, o_info, t)
+        g2, x2 = ob.observe(1)
+        assert bits_eq(r.obs_p2.cpu().numpy(), g2) and bits_eq(r.extra_p2.cpu().numpy(), x2)
+    b.check()
+
+
+def test_bullet_overflow_is_reported(torch_cuda):
+    """K = 2 slots: the third live bullet raises the sticky overflow error instead of corrupting state."""
+    from inversus_reinforcement_learning_amd import _lib as L
+    b = make(4, 15, 10, max_bullets=2, opponent="selfplay")
+    b.seed(np.arange(4)); b.reset()
+    p = b.get_state(("players",))["players"]
+    p[:, 0, :2] = (1, 5); p[:, 1, :2] = (13, 8)
+    b.set_state(players=p)
+    b.step(np.full(4, 10, np.uint8), np.zeros(4, np.uint8), obs=False)      # CHARGE RIGHT: 3 bullets into 2 slots
+    with pytest.raises(L.InversusError):
+        b.check()
+    assert np.all(b.get_state(("nbullets",))["nbullets"] <= 2)
+
+
+def test_stepping_after_round_over_matches_reference_semantics(torch_cuda):
+    """Without auto-reset a finished env keeps returning done and the terminal bonus (env_wrappers.py:408-422)."""
+    from oracle import oracle as orc
+    b = make(2, opponent="selfplay")
+    b.seed(np.array([5, 6])); b.reset()
+    envs = [orc.OracleEnv(15, 10, seed=s) for s in (5, 6)]
+    p = b.get_state(("players",))["players"]
+    p[:, 1, 4] = 0                                    # P2 dead in both envs
+    b.set_state(players=p)
+    for e in envs:
+        e.set_player(1, alive=0)
+    for t in range(3):
+        r = b.step(np.array([1, 6], np.uint8), np.zeros(2, np.uint8), reward64=True)
+        for i, e in enumerate(envs):
+            ro, do, info = e.step([1, 6][i], 0)
+            assert r.reward64[i].item() == ro and bool(r.done[i]) == do == True
+            assert bool(r.info_flags[i] & 4) == bool(info.win)
