@@ -428,24 +428,47 @@ __device__ __forceinline__ uint32_t apply_perm4(uint32_t list, uint32_t perm)
     return t;
 }
 
-// The draws: word block 0 = {u0, u1, u2, swap}, block 1 = shuffle A, block 2 = shuffle B; u = word * 2^-32
-// is only ever compared with a constant, so the compares are done on the integer word:
+// Draws of the device dummy: a counter hash, one 32-bit word per draw, generated only where a branch
+// consumes it (the reference draws from the process-global `random`, env_wrappers.py:96-155, which
+// cannot be reproduced per env; parity of the draws is statistical, parity of the decision function
+// given the draws is exact, tests/golden/g6_dummy.npz).
+//     key     = lowbias32(global_env * 0x9E3779B9 + seed)
+//     word(j) = lowbias32(key + (ctr * 16 + j) * 0x85EBCA6B)          ctr = per-env step counter
+// lowbias32 is the 2-multiply xorshift-multiply finaliser (bias 0.17); Philox4x32-10 cost ~100 scalar
+// instructions per env-step here, a fifth of the whole step, for draws that feed three coin flips.
+//   j = 0: u0 (shoot)   1: u1 (random move)   2: u2 (easy idle)   3: swap of the 2 candidates
+//   j = 4..6: shuffle A words   j = 8..10: shuffle B words
+// u = word * 2^-32 is only ever compared with a constant, so compares are done on the integer word:
 //   u < 0.2   <=> word <= 858993459      u < 0.05 <=> word <= 214748364      u > 0.001 <=> word >= 4294968
 // (0.2 * 2^32 = 858993459.2, 0.05 * 2^32 = 214748364.8, 0.001 * 2^32 = 4294967.296).
-// Blocks 1 and 2 are generated only on the branches that consume them.
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t dummy_word(uint32_t key, uint32_t ctr, uint32_t j)
+{
+    return lowbias32(key + (ctr * 16u + j) * 0x85EBCA6Bu);
+}
+
 template <class D>
 __device__ inline int dummy_action(const D &d, const uint32_t *g, const Env &e, int hard, uint32_t seed, uint32_t genv, uint32_t ctr)
 {
     const Player &p1 = e.p[0], &p2 = e.p[1];
     if (!p2.alive) return 0;                                               // :77-78
-    const U4 x = philox4x32(ctr, genv, 0u, kTagDummy, seed, kKey1);
-
-    const bool x_al = p2.x == p1.x, y_al = p2.y == p1.y;
-    if (hard && x.x <= 858993459u && p2.ammo > 0 && (x_al || y_al)) {     // :96-101, shoot_prob 0.2 (0 when easy)
-        if (x_al) return 5 + (p1.y < p2.y ? 0 : 2);
-        return 5 + (p1.x < p2.x ? 3 : 1);
+    const uint32_t key = lowbias32(genv * 0x9E3779B9u + seed);
+    if (!hard) {                                                           // easy: shoot_prob = random_move_prob = 0
+        if (dummy_word(key, ctr, 2u) >= 4294968u) return 0;                // :122-124, u2 > move_prob
+    } else {
+        const bool x_al = p2.x == p1.x, y_al = p2.y == p1.y;
+        if ((x_al || y_al) && p2.ammo > 0 && dummy_word(key, ctr, 0u) <= 858993459u) {   // :96-101, shoot_prob 0.2
+            if (x_al) return 5 + (p1.y < p2.y ? 0 : 2);
+            return 5 + (p1.x < p2.x ? 3 : 1);
+        }
     }
-    if (!hard && x.z >= 4294968u) return 0;                                // :122-124 (easy: random_move_prob is 0)
 
     // walkable-for-P2 mask over directions (in bounds and tile != WHITE), :116-118 etc.
     uint32_t walk = 0u;
@@ -455,9 +478,8 @@ __device__ inline int dummy_action(const D &d, const uint32_t *g, const Env &e, 
         if ((unsigned)nx < (unsigned)d.W && (unsigned)ny < (unsigned)d.H && rfl(tile_bit(g, ny * d.W + nx)) == 0u) walk |= 1u << dir;
     }
     uint32_t dirs = 0u | (2u << 4) | (3u << 8) | (1u << 12);               // [UP, DOWN, LEFT, RIGHT], :104
-    if (hard && x.y <= 214748364u) {                                       // :105-119, random_move_prob 0.05
-        const U4 y = philox4x32(ctr, genv, 1u, kTagDummy, seed, kKey1);
-        dirs = apply_perm4(dirs, fy_perm4(y.x, y.y, y.z));
+    if (hard && dummy_word(key, ctr, 1u) <= 214748364u) {                  // :105-119, random_move_prob 0.05
+        dirs = apply_perm4(dirs, fy_perm4(dummy_word(key, ctr, 4u), dummy_word(key, ctr, 5u), dummy_word(key, ctr, 6u)));
         const int c = (int)(dirs & 15u);
         if ((walk >> c) & 1u) return 1 + c;
     }
@@ -465,11 +487,10 @@ __device__ inline int dummy_action(const D &d, const uint32_t *g, const Env &e, 
     int c0 = -1, c1 = -1;
     if (dx != 0) c0 = dx > 0 ? 1 : 3;
     if (dy != 0) { const int c = dy > 0 ? 2 : 0; if (c0 < 0) c0 = c; else c1 = c; }
-    if (c1 >= 0 && __umulhi(x.w, 2u) == 0u) { const int t = c0; c0 = c1; c1 = t; }
+    if (c1 >= 0 && __umulhi(dummy_word(key, ctr, 3u), 2u) == 0u) { const int t = c0; c0 = c1; c1 = t; }
     if (c0 >= 0 && ((walk >> c0) & 1u)) return 1 + c0;                     // :140-152
     if (c1 >= 0 && ((walk >> c1) & 1u)) return 1 + c1;
-    const U4 z = philox4x32(ctr, genv, 2u, kTagDummy, seed, kKey1);
-    dirs = apply_perm4(dirs, fy_perm4(z.x, z.y, z.z));                      // :155-168
+    dirs = apply_perm4(dirs, fy_perm4(dummy_word(key, ctr, 8u), dummy_word(key, ctr, 9u), dummy_word(key, ctr, 10u)));   // :155-168
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (int)((dirs >> (4 * i)) & 15u);
