@@ -345,7 +345,7 @@ def test_full_size_properties(torch_cuda):
 
 
 # ------------------------------------------------------------------ ragged sizes, other K, overflow
-@pytest.mark.parametrize("n,W,H,K", [(1, 15, 10, 16), (3, 15, 10, 16), (5, 32, 32, 16), (7, 9, 4, 8), (130, 15, 10, 32),
+@pytest.mark.parametrize("n,W,H,K", [(1, 15, 10, 16), (3, 15, 10, 16), (5, 32, 32, 16), (7, 9, 4, 12), (130, 15, 10, 32),
                                      (6, 64, 3, 64), (9, 3, 64, 16)])
 def test_ragged_batches_and_other_bullet_capacities(torch_cuda, n, W, H, K):
     """N not a multiple of the 4 envs per block, K != 16, extreme aspect ratios (generic dims path)."""
