@@ -55,6 +55,19 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
     const int T = SINGLE ? 1 : a.T;
     for (int t = 0; t < T; ++t) {
         const size_t idx = (size_t)t * N + env;
+        // Output pointers: in the multi-step (rollout) variant they are re-read from the kernarg segment
+        // every step (10 scalar loads, K$-resident) instead of living in 20 SGPRs across the loop, which
+        // otherwise spills the wave's scalar state to VGPR lanes (348 v_readlane/v_writelane).
+        inv_step_out o;
+        typedef const volatile StepArgs __attribute__((address_space(4))) *KernargPtr;
+        const KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        if (SINGLE) {
+            o = a.o;
+        } else {
+            o.obs = ka->o.obs; o.extra = ka->o.extra; o.obs_p2 = ka->o.obs_p2; o.extra_p2 = ka->o.extra_p2;
+            o.reward = ka->o.reward; o.reward64 = ka->o.reward64; o.done = ka->o.done; o.info_flags = ka->o.info_flags;
+            o.episode_steps = ka->o.episode_steps; o.episode_return = ka->o.episode_return;
+        }
         if (t > 0) { act1v = a.a1[idx]; act2v = a.a2 ? (uint32_t)a.a2[idx] : 0u; }
         const int act1 = rfl((int)act1v);
         int act2;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
                 if (p1.alive && p1.ammo == 0) reward -= 0.001;
                 if (p1.alive && p2.alive) {
                     const int dist = abs(p1.x - p2.x) + abs(p1.y - p2.y);
-                    reward += a.s.prox[dist];
+                    reward += (SINGLE ? a.s.prox : ka->s.prox)[dist];
                     const bool aligned = p1.x == p2.x || p1.y == p2.y;
                     if (aligned) reward += 0.002;
                     if (act1 >= 5 && aligned && p1.ammo > 0) {
@@ -118,22 +131,35 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
         }
 
         if (lane == 0) {
-            if (a.o.reward) a.o.reward[idx] = (float)reward;
-            if (a.o.reward64) a.o.reward64[idx] = reward;
-            if (a.o.done) a.o.done[idx] = (uint8_t)done;
-            if (a.o.info_flags) a.o.info_flags[idx] = (uint8_t)info;
-            if (a.o.episode_steps) a.o.episode_steps[idx] = e.step_count;
-            if (a.o.episode_return) a.o.episode_return[idx] = e.ep_ret;
+            if (o.reward) o.reward[idx] = (float)reward;
+            if (o.reward64) o.reward64[idx] = reward;
+            if (o.done) o.done[idx] = (uint8_t)done;
+            if (o.info_flags) o.info_flags[idx] = (uint8_t)info;
+            if (o.episode_steps) o.episode_steps[idx] = e.step_count;
+            if (o.episode_return) o.episode_return[idx] = e.ep_ret;
         }
 
-        if (done && (a.flags & INV_STEP_AUTO_RESET)) reset_env(d, a.s, env, lane, g, L.scr, e);   // training.py:148-151
+        if (done && (a.flags & INV_STEP_AUTO_RESET)) {                                            // training.py:148-151
+            State rs = a.s;
+            if (!SINGLE) rs.mt = ka->s.mt;
+            reset_env(d, rs, env, lane, g, L.scr, e);
+        }
 
-        if (a.o.obs) render_obs(d, g, L.scr, tab, lane, 0, e, a.o.obs + idx * obs_stride, a.o.extra ? a.o.extra + idx * 4 : nullptr);
-        if (a.o.obs_p2) render_obs(d, g, L.scr, tab, lane, 1, e, a.o.obs_p2 + idx * obs_stride, a.o.extra_p2 ? a.o.extra_p2 + idx * 4 : nullptr);
+        if (o.obs) render_obs(d, g, L.scr, tab, lane, 0, e, o.obs + idx * obs_stride, o.extra ? o.extra + idx * 4 : nullptr);
+        if (o.obs_p2) render_obs(d, g, L.scr, tab, lane, 1, e, o.obs_p2 + idx * obs_stride, o.extra_p2 ? o.extra_p2 + idx * 4 : nullptr);
     }
 
-    store_env(d, a.s, env, lane, g, e);
-    if (err && lane == 0) atomicOr(a.s.err, err);
+    if (SINGLE) {
+        store_env(d, a.s, env, lane, g, e);
+        if (err && lane == 0) atomicOr(a.s.err, err);
+    } else {
+        typedef const volatile StepArgs __attribute__((address_space(4))) *KernargPtr;
+        const KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        State fs;
+        fs.head = ka->s.head; fs.grid = ka->s.grid; fs.bullets = ka->s.bullets; fs.mt = nullptr; fs.err = ka->s.err; fs.prox = nullptr;
+        store_env(d, fs, env, lane, g, e);
+        if (err && lane == 0) atomicOr(fs.err, err);
+    }
 }
 
 template <class D>

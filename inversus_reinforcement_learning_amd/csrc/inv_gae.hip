@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int kChunk = 16;
+constexpr int kChunk = 32;
 
 __device__ __forceinline__ float gae_step(float r, float v, float vnext, bool done, float gamma, float gl, float &last)
 {
@@ -40,6 +40,25 @@ __device__ __forceinline__ float gae_step(float r, float v, float vnext, bool do
     return last;
 }
 
+struct GaeChunk {
+    float r[kChunk], v[kChunk];
+    uint8_t d[kChunk];
+};
+
+// loads of time steps t, t-1, ..., t-kChunk+1 of column i (rows below 0 are clamped, never consumed)
+__device__ __forceinline__ void gae_load(GaeChunk &c, const float *__restrict__ r, const float *__restrict__ v,
+                                         const uint8_t *__restrict__ done, int t, int N, int i)
+{
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) {
+        const size_t idx = (size_t)max(t - k, 0) * N + i;
+        c.r[k] = r[idx]; c.v[k] = v[idx]; c.d[k] = done[idx];
+    }
+}
+
+// Only N lanes exist (one per env), i.e. 256 waves at N = 16 384 -- one per CU -- so the scan is bound by
+// memory latency, not bandwidth: the T loop is software-pipelined, the 3 x 32 loads of chunk c+1 are
+// in flight while the dependent chain of chunk c runs.
 __global__ __launch_bounds__(64) void k_gae_per_env(const float *__restrict__ r, const float *__restrict__ v,
                                                      const uint8_t *__restrict__ done, int T, int N, float gamma, float gl,
                                                      const float *__restrict__ last_value, float *__restrict__ adv,
@@ -49,31 +68,21 @@ __global__ __launch_bounds__(64) void k_gae_per_env(const float *__restrict__ r,
     if (i >= N) return;
     float vnext = last_value ? last_value[i] : 0.0f;
     float last = 0.0f;
-    int t = T - 1;
-    for (; t >= kChunk - 1; t -= kChunk) {
-        float rr[kChunk], vv[kChunk];
-        uint8_t dd[kChunk];
+    GaeChunk cur, nxt;
+    gae_load(cur, r, v, done, T - 1, N, i);
+    for (int t = T - 1; t >= 0; t -= kChunk) {
+        if (t - kChunk >= 0) gae_load(nxt, r, v, done, t - kChunk, N, i);
 #pragma unroll
-        for (int c = 0; c < kChunk; ++c) {
-            const size_t k = (size_t)(t - c) * N + i;
-            rr[c] = r[k]; vv[c] = v[k]; dd[c] = done[k];
+        for (int k = 0; k < kChunk; ++k) {
+            if (t - k >= 0) {
+                const size_t idx = (size_t)(t - k) * N + i;
+                const float a = gae_step(cur.r[k], cur.v[k], vnext, cur.d[k] != 0, gamma, gl, last);
+                adv[idx] = a;
+                ret[idx] = a + cur.v[k];
+                vnext = cur.v[k];
+            }
         }
-#pragma unroll
-        for (int c = 0; c < kChunk; ++c) {
-            const size_t k = (size_t)(t - c) * N + i;
-            const float a = gae_step(rr[c], vv[c], vnext, dd[c] != 0, gamma, gl, last);
-            adv[k] = a;
-            ret[k] = a + vv[c];
-            vnext = vv[c];
-        }
-    }
-    for (; t >= 0; --t) {
-        const size_t k = (size_t)t * N + i;
-        const float rv = r[k], vv = v[k];
-        const float a = gae_step(rv, vv, vnext, done[k] != 0, gamma, gl, last);
-        adv[k] = a;
-        ret[k] = a + vv;
-        vnext = vv;
+        cur = nxt;
     }
 }
 

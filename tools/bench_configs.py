@@ -29,6 +29,18 @@ for T in (8, 32):
     us = timeit(lambda: b.rollout(a1, None, out=out), reps=20, warm=3)
     res[f"rollout T={T} easy: us per vector step"] = us / T
     res[f"rollout T={T} easy: GB/s"] = bench.algorithmic_bytes_per_env_step() * n * T / us / 1e3
+# the same T steps as back-to-back single-step launches (pre-marshalled), same box
+b = DeviceEnvBatch(n, opponent="dummy", difficulty="easy", opp_seed=1)
+b.seed(np.arange(n, dtype=np.int64)); b.reset()
+T = 32
+a1 = torch.stack([b.uniform_actions(7, t) for t in range(T)])
+out1 = b._alloc_out((), True, False, False, None)
+stepper = b.make_stepper(out1, None, auto_reset=True)
+base = a1.data_ptr()
+def many():
+    for t in range(T):
+        stepper(base + t * n)
+res["32 single-step launches easy: us per vector step"] = timeit(many, reps=20, warm=3) / T
 # 32x32 stress (C5)
 for W, H in ((32, 32),):
     b = DeviceEnvBatch(n, W, H, opponent="dummy", difficulty="hard", opp_seed=1)
