@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--difficulty", default="easy", choices=["easy", "hard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse the control flow)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: put every rank on GPU 0 (a 1-GPU box cannot give each rank its own GPU)")
     args = ap.parse_args()
 
     import torch
@@ -90,10 +94,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    dev = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     n = NUM_ENVS
     off = rank * n                                   # contiguous global env range per rank
@@ -118,6 +126,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     # HIP events on the launch stream around groups of EV_GROUP consecutive k_step launches (an event
     # pair per launch costs ~2 us of queue markers per step); kernel_ms = group time / launches, so it
     # includes the ~1.5 us dependent-launch boundary between steps of one env batch.
@@ -135,10 +150,7 @@ def main():
     b.check()
 
     kern_ms = sum(s.elapsed_time(e) for s, e in ev) / args.steps
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt)
 
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_env_step() * n

@@ -397,3 +397,31 @@ def test_stepping_after_round_over_matches_reference_semantics(torch_cuda):
             ro, do, info = e.step([1, 6][i], 0)
             assert r.reward64[i].item() == ro and bool(r.done[i]) == do == True
             assert bool(r.info_flags[i] & 4) == bool(info.win)
+
+
+def test_step_is_hip_graph_capturable(torch_cuda):
+    """inv_step does no allocation / synchronisation, so a chain of steps can be captured in a HIP
+    graph and replayed (launch-bound inner loops); the replay equals eager stepping."""
+    torch = torch_cuda
+    n, T = 1024, 6
+    seeds = 300 + np.arange(n, dtype=np.int64)
+    eager = make(n, opponent="dummy", difficulty="hard", opp_seed=4)
+    graphed = make(n, opponent="dummy", difficulty="hard", opp_seed=4)
+    for b in (eager, graphed):
+        b.seed(seeds); b.reset()
+    a1 = torch.stack([eager.uniform_actions(9, t) for t in range(T)])
+    out = graphed._alloc_out((), True, False, False, None)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for t in range(T):
+            graphed.step(a1[t], None, auto_reset=True, out=out)
+    for rep in range(2):                                   # two replays == 2T eager steps
+        g.replay()
+        for t in range(T):
+            r = eager.step(a1[t], None, auto_reset=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out.obs, r.obs) and torch.equal(out.reward, r.reward) and torch.equal(out.done, r.done)
+    se, sg = eager.get_state(), graphed.get_state()
+    for k in se:
+        assert bits_eq(se[k], sg[k]), k
