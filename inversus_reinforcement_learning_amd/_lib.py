@@ -76,6 +76,9 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = _build.LIB
+    override = os.environ.get("INVERSUS_HIP_LIB")          # experiments: load another build of the same ABI
+    if override:
+        path, build_if_missing = override, False
     if build_if_missing:
         try:
             path = _build.build_library()

@@ -558,6 +558,7 @@ __device__ inline void render_obs(const D &d, const uint32_t *g, uint32_t *ob, c
     float4 *dst = reinterpret_cast<float4 *>(obs_env);
     const uint32_t sh = (uint32_t)(lane & 7) * 4u;
 #pragma unroll 4
+    // (default-policy stores: non-temporal stores measured 30.7 us vs 20.0 us for this stream)
     for (int j = lane; j < d.F4; j += kWave) dst[j] = tab[(ob[j >> 3] >> sh) & 15u];
     if (extra_env && lane < 4) {                                            // :238-243: f32(ammo / 6) computed in f64
         const Player &q = (lane & 1) ? en : me;

@@ -164,3 +164,26 @@ def train_vs_dummy(num_envs=1, total_steps=500_000, log_dir="runs/inversus_vs_du
 def train_selfplay(num_envs=1, total_steps=500_000, log_dir="runs/inversus_selfplay", load_model=None, *,
                    seed=None, width=15, height=10, agent_kwargs=None, verbose=True):
     return _train("selfplay", num_envs, total_steps, log_dir, "easy", load_model, seed, width, height, agent_kwargs, verbose)
+
+
+def main(argv=None):
+    """`python -m inversus_reinforcement_learning_amd.training --mode vs_dummy --num_envs 16384 ...`:
+    the reference's flags (training.py:378-407) without its 1..16 cap on --num_envs."""
+    import argparse
+    ap = argparse.ArgumentParser(description="Train an INVERSUS agent on the MI355X env")
+    ap.add_argument("--mode", choices=["vs_dummy", "selfplay"], default="vs_dummy")
+    ap.add_argument("--num_envs", type=int, default=4)
+    ap.add_argument("--total_steps", type=int, default=100_000)
+    ap.add_argument("--log_dir", type=str, default=None)
+    ap.add_argument("--opponent_difficulty", choices=["easy", "hard"], default="easy")
+    ap.add_argument("--load_model", type=str, default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    args = ap.parse_args(argv)
+    log_dir = args.log_dir or f"runs/inversus_{args.mode}"
+    if args.mode == "vs_dummy":
+        return train_vs_dummy(args.num_envs, args.total_steps, log_dir, args.opponent_difficulty, args.load_model, seed=args.seed)
+    return train_selfplay(args.num_envs, args.total_steps, log_dir, args.load_model, seed=args.seed)
+
+
+if __name__ == "__main__":
+    main()
