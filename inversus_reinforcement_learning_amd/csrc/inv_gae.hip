@@ -8,10 +8,9 @@
 //     ret = A + V[k]
 // The recurrence is sequential by nature; parallelism comes from independent chains.
 //
-//  * per_env: [T][N] buffers, one lane per env column -> loads/stores are coalesced across
-//    the env batch; the T loop is chunked so that a chunk's loads are all in flight before
-//    the dependent chain starts.  HBM-bound in principle (17 B per transition), latency-bound
-//    at N = 16 384 (256 waves on 256 CUs).
+//  * per_env: [T][N] buffers, one chain per env column; tiles of 32 columns x 128 steps are
+//    staged through LDS by a whole 256-thread block so that enough memory operations are in
+//    flight (see k_gae_per_env).  HBM-bound in principle: 17 B per transition.
 //  * reference_flat: the reference scans ONE chain over the env-interleaved buffer
 //    (training.py:128-137 fill order), so V[k+1] is the next env at the same timestep.  A
 //    `done` cuts the chain, so the buffer splits into independent segments, each ending at a
@@ -23,8 +22,6 @@
 #include "../../include/inversus_hip.h"
 
 namespace {
-
-constexpr int kChunk = 32;
 
 __device__ __forceinline__ float gae_step(float r, float v, float vnext, bool done, float gamma, float gl, float &last)
 {
@@ -40,49 +37,77 @@ __device__ __forceinline__ float gae_step(float r, float v, float vnext, bool do
     return last;
 }
 
-struct GaeChunk {
-    float r[kChunk], v[kChunk];
-    uint8_t d[kChunk];
-};
+// per_env scan, tiled through LDS.  Only N independent chains exist (one per env): with one lane per
+// chain the kernel runs 256 waves at N = 16 384, one per CU, bound by that wave's memory latency and by
+// the per-step dependent code (measured 1.5-1.7 TB/s).  So a 256-thread block owns a tile of
+// kGaeE = 32 env columns x kGaeT = 128 time steps and splits the work by what is truly sequential:
+//   1. all four waves stream r, V (plus the V row of step t+1) and done into LDS (coalesced 128-B rows);
+//   2. all threads compute, in parallel, the part of every step that does not depend on the chain:
+//        e = done ? r - V : (r + gamma*V') - V            (same roundings as the reference, in order)
+//   3. the first 32 lanes run the chains: A = done ? e : e + gamma_lam*A'  -- one multiply, one add and
+//      one select per step, LDS reads unrolled ahead of the dependent ops;
+//   4. all threads form ret = A + V and stream A, ret back.
+// ~69 KB of LDS per block -> two blocks per CU; T > 128 loops over tiles from the end carrying A'.
+constexpr int kGaeT = 128, kGaeE = 32, kGaeThreads = 256, kGaeRowsPerPass = kGaeThreads / kGaeE;
 
-// loads of time steps t, t-1, ..., t-kChunk+1 of column i (rows below 0 are clamped, never consumed)
-__device__ __forceinline__ void gae_load(GaeChunk &c, const float *__restrict__ r, const float *__restrict__ v,
-                                         const uint8_t *__restrict__ done, int t, int N, int i)
+__global__ __launch_bounds__(kGaeThreads) void k_gae_per_env(const float *__restrict__ r, const float *__restrict__ v,
+                                                              const uint8_t *__restrict__ done, int T, int N, float gamma,
+                                                              float gl, const float *__restrict__ last_value,
+                                                              float *__restrict__ adv, float *__restrict__ ret)
 {
-#pragma unroll
-    for (int k = 0; k < kChunk; ++k) {
-        const size_t idx = (size_t)max(t - k, 0) * N + i;
-        c.r[k] = r[idx]; c.v[k] = v[idx]; c.d[k] = done[idx];
-    }
-}
-
-// Only N lanes exist (one per env), i.e. 256 waves at N = 16 384 -- one per CU -- so the scan is bound by
-// memory latency, not bandwidth: the T loop is software-pipelined, the 3 x 32 loads of chunk c+1 are
-// in flight while the dependent chain of chunk c runs.
-__global__ __launch_bounds__(64) void k_gae_per_env(const float *__restrict__ r, const float *__restrict__ v,
-                                                     const uint8_t *__restrict__ done, int T, int N, float gamma, float gl,
-                                                     const float *__restrict__ last_value, float *__restrict__ adv,
-                                                     float *__restrict__ ret)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    float vnext = last_value ? last_value[i] : 0.0f;
+    __shared__ float se[kGaeT][kGaeE];           // r, then e (step 2), then A (step 3)
+    __shared__ float sv[kGaeT + 1][kGaeE];       // sv[k + 1] = V at tile row k; sv[0] = V of the step after the tile
+    __shared__ uint8_t sd[kGaeT][kGaeE];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * kGaeE;
+    const int c = tid & (kGaeE - 1), k0 = tid / kGaeE;           // this thread's column and first tile row
+    const bool col_ok = i0 + c < N;
+    const bool chain = tid < kGaeE && col_ok;
     float last = 0.0f;
-    GaeChunk cur, nxt;
-    gae_load(cur, r, v, done, T - 1, N, i);
-    for (int t = T - 1; t >= 0; t -= kChunk) {
-        if (t - kChunk >= 0) gae_load(nxt, r, v, done, t - kChunk, N, i);
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k) {
-            if (t - k >= 0) {
-                const size_t idx = (size_t)(t - k) * N + i;
-                const float a = gae_step(cur.r[k], cur.v[k], vnext, cur.d[k] != 0, gamma, gl, last);
-                adv[idx] = a;
-                ret[idx] = a + cur.v[k];
-                vnext = cur.v[k];
+
+    for (int thi = T - 1; thi >= 0; thi -= kGaeT) {
+        const int rows = min(kGaeT, thi + 1);                 // tile row k <-> time step thi - k
+        if (col_ok) {
+            if (k0 == 0) sv[0][c] = (thi + 1 < T) ? v[(size_t)(thi + 1) * N + i0 + c] : (last_value ? last_value[i0 + c] : 0.0f);
+#pragma unroll 8
+            for (int k = k0; k < rows; k += kGaeRowsPerPass) {
+                const size_t idx = (size_t)(thi - k) * N + i0 + c;
+                se[k][c] = r[idx]; sv[k + 1][c] = v[idx]; sd[k][c] = done[idx];
             }
         }
-        cur = nxt;
+        __syncthreads();
+        if (col_ok) {
+#pragma unroll 8
+            for (int k = k0; k < rows; k += kGaeRowsPerPass) {
+                const float rr = se[k][c], vv = sv[k + 1][c], vn = sv[k][c];
+                const float gv = gamma * vn;
+                const float sum = rr + gv;
+                const float d_nd = sum - vv;                  // (r + gamma*V') - V
+                const float d_d = rr - vv;                    // r - V
+                se[k][c] = sd[k][c] ? d_d : d_nd;
+            }
+        }
+        __syncthreads();
+        if (chain) {
+#pragma unroll 16
+            for (int k = 0; k < rows; ++k) {
+                const float e = se[k][tid];
+                const float g2 = gl * last;
+                const float cand = e + g2;
+                last = sd[k][tid] ? e : cand;
+                se[k][tid] = last;
+            }
+        }
+        __syncthreads();
+        if (col_ok) {
+#pragma unroll 8
+            for (int k = k0; k < rows; k += kGaeRowsPerPass) {
+                const size_t idx = (size_t)(thi - k) * N + i0 + c;
+                const float a = se[k][c];
+                adv[idx] = a; ret[idx] = a + sv[k + 1][c];
+            }
+        }
+        __syncthreads();                                      // se / sv / sd are rewritten by the next tile
     }
 }
 
@@ -116,7 +141,7 @@ extern "C" int inv_gae(const float *r, const float *v, const uint8_t *done, int3
     if (!r || !v || !done || !adv || !ret || T < 1 || N < 1) return INV_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (layout == INV_GAE_PER_ENV) {
-        hipLaunchKernelGGL(k_gae_per_env, dim3((N + 63) / 64), dim3(64), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
+        hipLaunchKernelGGL(k_gae_per_env, dim3((N + kGaeE - 1) / kGaeE), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
     } else if (layout == INV_GAE_REFERENCE_FLAT) {
         const long long n = (long long)T * N;
         hipLaunchKernelGGL(k_gae_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r, v, done, n, gamma, gamma_lam, last_value, adv, ret);

@@ -233,7 +233,8 @@ def gae(rewards, values, dones, gamma=0.99, lam=0.95, last_value=None, layout="p
     lib = L.load()
     r = rewards.contiguous().float()
     v = values.contiguous().float()
-    d = dones.contiguous().to(torch.uint8)
+    d = dones.contiguous()
+    d = d.view(torch.uint8) if d.dtype == torch.bool else d.to(torch.uint8)     # bool -> u8 is a reinterpretation, no copy
     if r.dim() == 1:
         r, v, d = r[:, None], v[:, None], d[:, None]
     T, N = r.shape
