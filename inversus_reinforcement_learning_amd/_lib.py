@@ -40,6 +40,14 @@ class InvStateView(C.Structure):
                 ("opp_ctr", C.c_void_p), ("mt", C.c_void_p), ("mt_index", C.c_void_p)]
 
 
+class InvPolicyLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("lnw", C.c_void_p), ("lnb", C.c_void_p)]
+
+
+class InvPolicyParams(C.Structure):
+    _fields_ = [("layer", InvPolicyLayer * 4)]
+
+
 _V = C.c_void_p
 SIGNATURES = {
     "inv_last_error": (C.c_char_p, []),
@@ -61,6 +69,7 @@ SIGNATURES = {
     "inv_gae": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_float, C.c_float, _V, C.c_int32, _V, _V, _V]),
     "inv_uniform_actions": (C.c_int, [_V, C.c_int32, C.c_uint32, C.c_int64, C.c_uint32, _V]),
     "inv_rollout": (C.c_int, [_V, C.c_int32, _V, _V, P(InvStepOut), _V]),
+    "inv_policy_trunk": (C.c_int, [P(InvPolicyParams), _V, _V, C.c_int32, _V]),
 }
 
 _lib = None

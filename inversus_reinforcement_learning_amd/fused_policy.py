@@ -1,0 +1,87 @@
+"""Fused forward of InversusCNNPolicy for rollouts.
+
+The convolutional trunk (conv1..4 + LayerNorm + ReLU + residual, policies.py:91-99) runs in ONE
+HIP kernel per batch (csrc/inv_policy.hip: bf16 MFMA, activations resident in LDS); the two MLP heads
+run as plain bf16/f32 GEMMs (one concatenated [512 x 19204] first layer for actor and critic).
+Weights are re-packed from the f32 `nn.Module` by `refresh()` -- call it after every optimizer step
+you want the actor to see.  Inference only: the PPO update keeps using the autograd module.
+
+Numerics: bf16 operands with f32 accumulation, i.e. NOT bit-equal to the f32 module; logits agree to
+~1e-2 (tests/test_gpu_policy.py).  Only the 12 x 10 x 15 observation of the reference is supported.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_CIN_PAD = (16, 32, 64, 128)
+
+
+def _pack_conv(w, cin_pad):
+    """[Cout, Cin, 3, 3] f32 -> bf16 [Cout/32][9*cin_pad/16][64][8] MFMA A fragments (see inversus_hip.h)."""
+    cout, cin = w.shape[:2]
+    wp = torch.zeros(cout, 3, 3, cin_pad, dtype=torch.float32, device=w.device)
+    wp[..., :cin] = w.permute(0, 2, 3, 1)                       # k = (3*ky + kx) * cin_pad + c
+    k = 9 * cin_pad
+    wk = wp.reshape(cout // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4)   # [mt][ks][h][r][8]
+    return wk.reshape(cout // 32, k // 16, 64, 8).contiguous().to(torch.bfloat16)
+
+
+class FusedPolicy:
+    """Callable like the module in eval mode: (grid f32 [B,12,10,15], extra f32 [B,4]) -> (logits, value)."""
+
+    def __init__(self, policy):
+        self.policy = policy
+        self.lib = L.load()
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        p = self.policy
+        dev = p.conv1.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedPolicy needs the policy on the GPU")
+        if tuple(p.norm1.normalized_shape) != (32, 10, 15) or p.conv1.in_channels != 12:
+            raise ValueError("the fused trunk supports the reference's 12 x 10 x 15 observation only")
+        self._keep = []
+        params = L.InvPolicyParams()
+        for i, (conv, norm) in enumerate(((p.conv1, p.norm1), (p.conv2, p.norm2), (p.conv3, p.norm3), (p.conv4, p.norm4))):
+            cout = conv.out_channels
+            w = _pack_conv(conv.weight.detach().float(), _CIN_PAD[i])
+            b = conv.bias.detach().float().contiguous()
+            lnw = norm.weight.detach().float().reshape(cout, 150).t().contiguous()     # [pixel][channel]
+            lnb = norm.bias.detach().float().reshape(cout, 150).t().contiguous()
+            self._keep += [w, b, lnw, lnb]
+            params.layer[i] = L.InvPolicyLayer(w.data_ptr(), b.data_ptr(), lnw.data_ptr(), lnb.data_ptr())
+        self.params = params
+        # heads: first Linear of actor and critic concatenated; columns permuted from the module's
+        # flatten order (c*150 + pixel) to the kernel's channels-last order (pixel*128 + c)
+        w1 = torch.cat([p.fc_actor[0].weight, p.fc_critic[0].weight]).detach().float()      # [512, 19204]
+        hid = w1.shape[0]
+        self.w1_feat = w1[:, :19200].reshape(hid, 128, 150).permute(0, 2, 1).reshape(hid, 19200).contiguous().to(torch.bfloat16)
+        self.w1_extra = w1[:, 19200:].contiguous()
+        self.b1 = torch.cat([p.fc_actor[0].bias, p.fc_critic[0].bias]).detach().float()
+        self.hidden = p.fc_actor[0].out_features
+
+    @torch.no_grad()
+    def features(self, grid):
+        """Trunk only: bf16 [B, 19200] in channels-last order."""
+        grid = grid.contiguous().float()
+        feat = torch.empty((grid.shape[0], 19200), dtype=torch.bfloat16, device=grid.device)
+        with torch.cuda.device(grid.device):
+            rc = self.lib.inv_policy_trunk(C.byref(self.params), C.c_void_p(grid.data_ptr()), C.c_void_p(feat.data_ptr()),
+                                           grid.shape[0], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.raise_for(rc, self.lib)
+        return feat
+
+    @torch.no_grad()
+    def __call__(self, grid, extra):
+        p = self.policy
+        feat = self.features(grid)
+        h = (feat @ self.w1_feat.t()).float() + extra.float() @ self.w1_extra.t() + self.b1
+        h = torch.relu(h)
+        ha, hc = h[:, :self.hidden], h[:, self.hidden:]
+        logits = p.fc_actor[4](torch.relu(p.fc_actor[2](ha)))
+        value = p.fc_critic[4](torch.relu(p.fc_critic[2](hc)))
+        return logits, value
