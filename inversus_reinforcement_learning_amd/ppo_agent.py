@@ -25,7 +25,8 @@ from .device_env import gae as device_gae
 
 class PPOAgent:
     def __init__(self, policy, lr=1e-4, gamma=0.99, lam=0.95, clip_ratio=0.2, epochs=4, batch_size=512,
-                 entropy_coef=0.02, value_coef=0.1, device="cuda", *, gae_layout="per_env", max_grad_norm=0.5):
+                 entropy_coef=0.02, value_coef=0.1, device="cuda", *, gae_layout="per_env", max_grad_norm=0.5,
+                 fused_act=False):
         self.device = torch.device(device)
         self.policy = policy.to(self.device)
         self.gamma, self.lam, self.clip_ratio = gamma, lam, clip_ratio
@@ -35,6 +36,13 @@ class PPOAgent:
         self.optimizer = optim.Adam(self.policy.parameters(), lr=lr)
         _, w = parallel.world()
         self.reducer = parallel.FlatGradReducer(self.policy.parameters()) if w > 1 else None
+        # fused_act: rollouts use the fused bf16 trunk kernel (csrc/inv_policy.hip) instead of the f32
+        # module; log-probs / values stored in the buffer then come from bf16 operands (~1e-2 off the f32
+        # recomputation in update(), i.e. the PPO ratio starts at 1 +- 1e-2).  Default off = reference numerics.
+        self.fused = None
+        if fused_act:
+            from .fused_policy import FusedPolicy
+            self.fused = FusedPolicy(self.policy)
         self.reset_buffers()
 
     # ------------------------------------------------------------------ buffers (ppo_agent.py:58-66, 108-125)
@@ -69,7 +77,8 @@ class PPOAgent:
         tensors out (actions int64, log_probs f32, values f32)."""
         as_numpy = not isinstance(grid_tensors, torch.Tensor)
         self.policy.eval()
-        logits, values = self.policy(self._t(grid_tensors, torch.float32), self._t(extra_vectors, torch.float32))
+        fwd = self.fused if self.fused is not None else self.policy
+        logits, values = fwd(self._t(grid_tensors, torch.float32), self._t(extra_vectors, torch.float32))
         dist = torch.distributions.Categorical(logits=logits)
         actions = dist.sample()
         log_probs = dist.log_prob(actions)
@@ -154,5 +163,7 @@ class PPOAgent:
                 tot_e += entropy.detach()
                 num_updates += 1
         self.reset_buffers()
+        if self.fused is not None:
+            self.fused.refresh()                                          # re-pack the updated weights for the actor
         return {"policy_loss": float(tot_p) / num_updates, "value_loss": float(tot_v) / num_updates,
                 "entropy": float(tot_e) / num_updates}

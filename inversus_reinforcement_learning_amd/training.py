@@ -61,7 +61,8 @@ class RolloutCollector:
 
     @torch.no_grad()
     def _opponent_actions(self):
-        self.opponent.eval()
+        if hasattr(self.opponent, "eval"):
+            self.opponent.eval()
         logits, _ = self.opponent(self.obs_p2[0], self.obs_p2[1])
         return torch.distributions.Categorical(logits=logits).sample().to(torch.uint8)
 
@@ -120,6 +121,10 @@ def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, w
         opponent.load_state_dict(policy.state_dict())               # initial opponent is a clone (training.py:239)
         opponent.eval()
     agent = PPOAgent(policy, **(agent_kwargs or {}))
+    opp_module = opponent
+    if opponent is not None and agent.fused is not None:
+        from .fused_policy import FusedPolicy
+        opponent = FusedPolicy(opp_module)                          # the frozen opponent acts through the fused trunk too
     collector = RolloutCollector(batch, agent, opponent)
     logger = TrainingLogger(log_dir) if (log_dir and rank == 0) else None
 
@@ -132,7 +137,9 @@ def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, w
         step_count += todo * num_envs
         stats = agent.update()
         if mode == "selfplay" and step_count - last_refresh >= 20000:   # training.py:265,331-334
-            opponent.load_state_dict(policy.state_dict())
+            opp_module.load_state_dict(policy.state_dict())
+            if opponent is not opp_module:
+                opponent.refresh()
             last_refresh = step_count
         ep = collector.episodes
         episode_count = len(ep["return"]) * world_size

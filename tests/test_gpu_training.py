@@ -95,3 +95,11 @@ def test_act_numpy_contract_and_store_step():
     adv, ret = agent.compute_advantages()
     assert adv.shape == (4,) and adv.dtype == np.float32
     assert isinstance(agent.update(), dict)
+
+
+def test_training_loop_with_fused_actor(tmp_path):
+    """Self-play loop with the fused bf16 trunk acting for both the learner and the frozen opponent."""
+    from inversus_reinforcement_learning_amd import training
+    res = training.train_selfplay(num_envs=64, total_steps=64 * 128, log_dir=str(tmp_path / "fused"), seed=4, verbose=False,
+                                  agent_kwargs=dict(batch_size=2048, epochs=1, fused_act=True))
+    assert res["steps"] == 64 * 128 and np.isfinite(res["policy_loss"]) and np.isfinite(res["entropy"])

@@ -82,17 +82,20 @@ for layout in ("per_env", "reference_flat"):
 from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
 from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
 from inversus_reinforcement_learning_amd.training import RolloutCollector
-for nn_ in (2048, 16384):
-    b = DeviceEnvBatch(nn_, opponent="selfplay")
-    b.seed(np.arange(nn_, dtype=np.int64)); b.reset()
-    torch.manual_seed(0)
-    pol = InversusCNNPolicy(12, 10, 15, 4).cuda(); opp = InversusCNNPolicy(12, 10, 15, 4).cuda()
-    agent = PPOAgent(pol)
-    col = RolloutCollector(b, agent, opp)
-    col.collect(2); agent.reset_buffers(); torch.cuda.synchronize()
-    t0 = time.perf_counter(); col.collect(6); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    agent.reset_buffers()
-    res[f"selfplay collector (f32 torch CNN x2) N={nn_}: env-steps/s"] = 6 * nn_ / dt
-    del col, agent, pol, opp, b
-    torch.cuda.empty_cache()
+from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+for fused in (False, True):
+    for nn_ in (2048, 16384):
+        b = DeviceEnvBatch(nn_, opponent="selfplay")
+        b.seed(np.arange(nn_, dtype=np.int64)); b.reset()
+        torch.manual_seed(0)
+        pol = InversusCNNPolicy(12, 10, 15, 4).cuda(); opp = InversusCNNPolicy(12, 10, 15, 4).cuda()
+        agent = PPOAgent(pol, fused_act=fused)
+        col = RolloutCollector(b, agent, FusedPolicy(opp) if fused else opp)
+        col.collect(2); agent.reset_buffers(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); col.collect(6); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        agent.reset_buffers()
+        tag = "fused bf16 trunk" if fused else "f32 torch CNN"
+        res[f"selfplay collector ({tag} x2) N={nn_}: env-steps/s"] = 6 * nn_ / dt
+        del col, agent, pol, opp, b
+        torch.cuda.empty_cache()
 print(json.dumps(res, indent=1))

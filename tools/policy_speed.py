@@ -40,3 +40,15 @@ def fb(dtype):
 res["fwd+bwd f32 B=2048 ms"] = t(fb(None))
 res["fwd+bwd bf16 B=2048 ms"] = t(fb(torch.bfloat16))
 print(json.dumps(res, indent=1))
+
+# fused trunk (csrc/inv_policy.hip)
+from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+pol.eval()
+fused = FusedPolicy(pol)
+res2 = {}
+for B in (2048, 16384):
+    g = (torch.rand(B, 12, 10, 15, device="cuda") < 0.2).float(); x = torch.rand(B, 4, device="cuda")
+    res2[f"fused trunk B={B} ms"] = t(lambda: fused.features(g))
+    res2[f"fused trunk+heads B={B} ms"] = t(lambda: fused(g, x))
+    res2[f"fused trunk B={B} TFLOP/s (72.9 MFLOP/sample)"] = 72.9e6 * B / (res2[f"fused trunk B={B} ms"] * 1e-3) / 1e12
+print(json.dumps(res2, indent=1))
