@@ -174,9 +174,9 @@ int  inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2,
 /* ---- fused policy trunk -------------------------------------------------
  * conv1..conv4 + LayerNorm([C,H,W]) + ReLU (+ residual) of InversusCNNPolicy.forward
  * (inversus_rl/policies.py:91-99) for the 10 x 15 board, bf16 MFMA / f32 accumulate, one workgroup
- * per sample.  Per layer l (Cin_pad = 16, 32, 64, 128; Cout = 32, 64, 128, 128):
- *   w    bf16 [Cout/32][9*Cin_pad/16][64][8]  A fragments: lane = 32*h + r holds
- *                                             W[cout = 32*mt + r][k = 16*ks + 8*h + j], k = (3*ky+kx)*Cin_pad + c
+ * per sample.  Per layer l (Cin_pad = 32, 32, 64, 128; Cout = 32, 64, 128, 128):
+ *   w    bf16 [Cout/16][9*Cin_pad/32][64][8]  A fragments of v_mfma_f32_16x16x32_bf16: lane = 16*g + r holds
+ *                                             W[cout = 16*mt + r][k = 32*ks + 8*g + j], k = (3*ky+kx)*Cin_pad + c
  *   bias f32  [Cout]
  *   lnw, lnb f32 [150][Cout]                  LayerNorm affine, transposed to [pixel][channel]
  * obs: f32 [N][12][10][15] (what inv_step writes); feat: bf16 [N][150][128] channels-last, i.e.

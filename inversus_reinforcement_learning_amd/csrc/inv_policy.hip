@@ -27,19 +27,22 @@
 
 #include "../../include/inversus_hip.h"
 
+// bf16 pipeline, not bit-comparable with the f32 module anyway: let the epilogue use FMAs even though the
+// library is built with -ffp-contract=off for the env / GAE kernels
+#pragma clang fp contract(fast)
+
 namespace pol {
 
 constexpr int H = 10, W = 15, P = H * W;                 // 150 pixels
 constexpr int PW = W + 2, PH = H + 2, NPOS = PW * PH;    // 12 x 17 haloed tile, 204 positions
 constexpr int CSTRIDE = 136;                             // bf16 per position: 128 channels + 8 pad = 272 B
-constexpr int NT = 5;                                    // pixel tiles of 32 (160 >= 150)
-constexpr int THREADS = 256;
+constexpr int THREADS = 512, WAVES = THREADS / 64;       // 8 waves = 2 per SIMD
 constexpr float LN_EPS = 1e-5f;
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ int pos_of(int p) { return (p / W + 1) * PW + (p % W) + 1; }
 
@@ -50,103 +53,127 @@ __device__ __forceinline__ float wave_sum(float x)
     return x;
 }
 
-// One conv3x3 (pad 1) + bias (+ residual) + LayerNorm over the whole sample + ReLU.
-// in / out: haloed channels-last LDS tiles; CIN is the padded input channel count (multiple of 16).
-template <int CIN, int COUT, bool RESIDUAL>
+// One conv3x3 (pad 1) + bias (+ residual) + LayerNorm over the whole sample + ReLU, as an implicit GEMM on
+// v_mfma_f32_16x16x32_bf16:  D[cout][pixel] += W[cout][k] . X[k][pixel],  k-step = (tap, 32 channels).
+//   A fragment (weights, global, pre-packed):  lane l holds W[16*mt + (l&15)][32*ks + 8*(l>>4) + j]
+//   B fragment (activations, LDS):             lane l holds X[channel 32*kc + 8*(l>>4) + j][pixel 16*nt + (l&15)]
+//                                              = 16 contiguous bytes of the channels-last tile
+//   accumulator:                               reg q of lane l = D[16*mt + 4*(l>>4) + q][16*nt + (l&15)]
+// Work split over the 8 waves: MW row blocks x NW pixel tiles per wave (150 pixels = 10 tiles of 16, so the
+// two halves of the workgroup take 5 tiles each -- no ragged tile, no predication in the main loop).
+// The k loop is software-pipelined by hand: the weight fragments of tap t+1 and the activation fragments of
+// k-step s+1 are in flight while the MFMAs of k-step s issue (hipcc does not do this on its own: the first
+// version waited on every ds_read and on the L2 load of the next weights inside each k-step).
+template <int CIN, int COUT, int MW, int NW, bool RAGGED, bool RESIDUAL>
 __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, const bf16 *__restrict__ in, bf16 *__restrict__ out,
-                                             float *red, int lane, int wave)
+                                             float *red, int lane, int m0, int n0, int ncount)
 {
-    constexpr int MT = COUT / 32, KPT = CIN / 16, KS = 9 * KPT;
-    const int r = lane & 31, h = lane >> 5;
-    // tile ownership: one 32-channel row block per wave, as many pixel tiles as it takes
-    int m, n0, nstride, ncount;
-    if (MT == 4) { m = wave; n0 = 0; nstride = 1; ncount = 5; }
-    else if (MT == 2) { m = wave & 1; n0 = (wave >> 1) * 3; nstride = 1; ncount = (wave >> 1) ? 2 : 3; }
-    else { m = 0; n0 = wave; nstride = 4; ncount = wave == 0 ? 2 : 1; }
+    constexpr int KPT = CIN / 32, KS = 9 * KPT;
+    const int c16 = lane & 15, kg = lane >> 4;
 
-    int pix[NT], base[NT];
+    int pix[NW], base[NW];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        pix[i] = (n0 + i * nstride) * 32 + r;
-        base[i] = pos_of(min(pix[i], P - 1)) * CSTRIDE + 8 * h;     // columns >= 150 read pixel 149; never stored
+    for (int i = 0; i < NW; ++i) {
+        pix[i] = (n0 + i) * 16 + c16;
+        base[i] = pos_of(min(pix[i], P - 1)) * CSTRIDE;             // columns >= 150 read pixel 149; never stored
     }
 
-    f32x16 acc[NT];
+    f32x4 acc[MW][NW];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
 
-    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m * KS * 64 + lane;
-    bf16x8 a_next = wp[0];
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        const int toff = ((tap / 3 - 1) * PW + (tap % 3 - 1)) * CSTRIDE;
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
+    bf16x8 a_cur[MW], a_nxt[MW], b_cur[NW], b_nxt[NW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) a_cur[mi] = wp[(size_t)mi * KS * 64];
+    {
+        const int off0 = (-PW - 1) * CSTRIDE + 8 * kg;             // tap (0,0), channel group 0
+#pragma unroll
+        for (int i = 0; i < NW; ++i) b_cur[i] = *reinterpret_cast<const bf16x8 *>(in + base[i] + off0);
+    }
 #pragma unroll 2
-        for (int kc = 0; kc < KPT; ++kc) {
-            const int ks = tap * KPT + kc;
-            const bf16x8 a = a_next;
-            if (ks + 1 < KS) a_next = wp[(size_t)(ks + 1) * 64];
+    for (int ks = 0; ks < KS; ++ks) {
+        // fragments of k-step ks+1 (the last prefetch is redundant but in bounds)
+        const int ksn = ks + 1 < KS ? ks + 1 : ks;
+        const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
+        const int off_n = ((tapn / 3 - 1) * PW + (tapn % 3 - 1)) * CSTRIDE + kcn * 32 + 8 * kg;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                if (i < ncount) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(in + base[i] + toff + kc * 16);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
-                }
-            }
-        }
+        for (int mi = 0; mi < MW; ++mi) a_nxt[mi] = wp[((size_t)mi * KS + ksn) * 64];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) b_nxt[i] = *reinterpret_cast<const bf16x8 *>(in + base[i] + off_n);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                if (!RAGGED || i < ncount)
+                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[mi], b_cur[i], acc[mi][i], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) a_cur[mi] = a_nxt[mi];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) b_cur[i] = b_nxt[i];
     }
 
-    // bias (+ residual), LayerNorm statistics.  Register v of a lane: channel m*32 + 8*(v>>2) + 4*h + (v&3), pixel pix[i].
+    // LayerNorm affine parameters of this lane's outputs: issue the loads now, they land during the reduction
+    float4 lw[MW][NW], lb[MW][NW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const size_t o = (size_t)min(pix[i], P - 1) * COUT + (m0 + mi) * 16 + 4 * kg;
+            lw[mi][i] = *reinterpret_cast<const float4 *>(lp.lnw + o);
+            lb[mi][i] = *reinterpret_cast<const float4 *>(lp.lnb + o);
+        }
+
+    // bias (+ residual) and the LayerNorm statistics
     float s = 0.0f, ss = 0.0f;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        if (i < ncount) {
-            const bool valid = pix[i] < P;
-            const int ipos = pos_of(min(pix[i], P - 1)) * CSTRIDE;
+    for (int mi = 0; mi < MW; ++mi) {
+        const int ch0 = (m0 + mi) * 16 + 4 * kg;
+        const float4 bq = *reinterpret_cast<const float4 *>(lp.bias + ch0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch0 = m * 32 + 8 * g + 4 * h;
-                const float4 bq = *reinterpret_cast<const float4 *>(lp.bias + ch0);
-                float x0 = acc[i][4 * g + 0] + bq.x, x1 = acc[i][4 * g + 1] + bq.y;
-                float x2 = acc[i][4 * g + 2] + bq.z, x3 = acc[i][4 * g + 3] + bq.w;
-                if (RESIDUAL) {
-                    const bf16x4 rq = *reinterpret_cast<const bf16x4 *>(in + ipos + ch0);
-                    x0 += (float)rq[0]; x1 += (float)rq[1]; x2 += (float)rq[2]; x3 += (float)rq[3];
-                }
-                acc[i][4 * g + 0] = x0; acc[i][4 * g + 1] = x1; acc[i][4 * g + 2] = x2; acc[i][4 * g + 3] = x3;
-                if (valid) {
-                    s += (x0 + x1) + (x2 + x3);
-                    ss += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
-                }
+        for (int i = 0; i < NW; ++i) {
+            float x0 = acc[mi][i][0] + bq.x, x1 = acc[mi][i][1] + bq.y, x2 = acc[mi][i][2] + bq.z, x3 = acc[mi][i][3] + bq.w;
+            if (RESIDUAL) {
+                const bf16x4 rq = *reinterpret_cast<const bf16x4 *>(in + base[i] + ch0);
+                x0 += (float)rq[0]; x1 += (float)rq[1]; x2 += (float)rq[2]; x3 += (float)rq[3];
+            }
+            acc[mi][i][0] = x0; acc[mi][i][1] = x1; acc[mi][i][2] = x2; acc[mi][i][3] = x3;
+            if (i < ncount && pix[i] < P) {
+                s += (x0 + x1) + (x2 + x3);
+                ss += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
             }
         }
     }
     s = wave_sum(s);
     ss = wave_sum(ss);
-    if (lane == 0) { red[wave] = s; red[4 + wave] = ss; }
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = s; red[WAVES + wave] = ss; }
     __syncthreads();
     const float cnt = (float)(COUT * P);
-    const float S = (red[0] + red[1]) + (red[2] + red[3]), SS = (red[4] + red[5]) + (red[6] + red[7]);
+    float S = 0.0f, SS = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { S += red[w]; SS += red[WAVES + w]; }
     const float mean = S / cnt;
     const float var = fmaxf(SS / cnt - mean * mean, 0.0f);
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    const float shift = -mean * rstd;
 
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        if (i < ncount && pix[i] < P) {
-            const int opos = pos_of(pix[i]) * CSTRIDE;
+    for (int mi = 0; mi < MW; ++mi) {
+        const int ch0 = (m0 + mi) * 16 + 4 * kg;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch0 = m * 32 + 8 * g + 4 * h;
-                const float4 wq = *reinterpret_cast<const float4 *>(lp.lnw + (size_t)pix[i] * COUT + ch0);
-                const float4 bq = *reinterpret_cast<const float4 *>(lp.lnb + (size_t)pix[i] * COUT + ch0);
+        for (int i = 0; i < NW; ++i) {
+            if (i < ncount && pix[i] < P) {
                 bf16x4 o;
-                o[0] = (bf16)fmaxf((acc[i][4 * g + 0] - mean) * rstd * wq.x + bq.x, 0.0f);
-                o[1] = (bf16)fmaxf((acc[i][4 * g + 1] - mean) * rstd * wq.y + bq.y, 0.0f);
-                o[2] = (bf16)fmaxf((acc[i][4 * g + 2] - mean) * rstd * wq.z + bq.z, 0.0f);
-                o[3] = (bf16)fmaxf((acc[i][4 * g + 3] - mean) * rstd * wq.w + bq.w, 0.0f);
-                *reinterpret_cast<bf16x4 *>(out + opos + ch0) = o;
+                o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), lw[mi][i].x, lb[mi][i].x), 0.0f);
+                o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), lw[mi][i].y, lb[mi][i].y), 0.0f);
+                o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), lw[mi][i].z, lb[mi][i].z), 0.0f);
+                o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), lw[mi][i].w, lb[mi][i].w), 0.0f);
+                *reinterpret_cast<bf16x4 *>(out + base[i] + ch0) = o;
             }
         }
     }
@@ -157,7 +184,7 @@ __global__ __launch_bounds__(THREADS) void k_policy_trunk(inv_policy_params prm,
                                                           bf16 *__restrict__ feat, int N)
 {
     __shared__ __attribute__((aligned(16))) bf16 tile[2][NPOS * CSTRIDE];      // 2 x 55 488 B
-    __shared__ float red[8];
+    __shared__ float red[2 * WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // zero both tiles once: the halo and the pad channels stay zero for the life of the block
@@ -170,18 +197,27 @@ __global__ __launch_bounds__(THREADS) void k_policy_trunk(inv_policy_params prm,
     __syncthreads();
 
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
-        // observation f32 [12][150] -> tile 0, channels-last, 16 channels (12..15 zero)
+        // Per-lane addresses (LDS fragment bases, LayerNorm parameter pointers of all four layers: ~160
+        // registers) are invariant over this loop; hipcc hoists them out and then spills them to scratch
+        // around the MFMA loops.  Laundering the lane id makes them cheap per-sample recomputations instead.
+        int lane_i = lane;
+        asm volatile("" : "+v"(lane_i));
+        // observation f32 [12][150] -> tile 0, channels-last, 32 channels (12..31 zero: the k-step is 32 wide)
         const float *o = obs + (size_t)n * 12 * P;
-        for (int e = tid; e < 16 * P; e += THREADS) {
+        for (int e = tid; e < 32 * P; e += THREADS) {
             const int c = e / P, p = e - c * P;
             const float val = c < 12 ? o[c * P + p] : 0.0f;
             tile[0][pos_of(p) * CSTRIDE + c] = (bf16)val;
         }
         __syncthreads();
-        conv_ln_relu<16, 32, false>(prm.layer[0], tile[0], tile[1], red, lane, wave);
-        conv_ln_relu<32, 64, false>(prm.layer[1], tile[1], tile[0], red, lane, wave);
-        conv_ln_relu<64, 128, false>(prm.layer[2], tile[0], tile[1], red, lane, wave);
-        conv_ln_relu<128, 128, true>(prm.layer[3], tile[1], tile[0], red, lane, wave);
+        // tile ownership (8 waves): conv1: 2 row blocks x (3,3,2,2) pixel tiles; conv2: 4 x (5,5); conv3/4: 4 x 2 row blocks x (5,5)
+        {
+            const int g = wave >> 1;
+            conv_ln_relu<32, 32, 1, 3, true, false>(prm.layer[0], tile[0], tile[1], red, lane_i, wave & 1, g < 2 ? g * 3 : 6 + (g - 2) * 2, g < 2 ? 3 : 2);
+        }
+        conv_ln_relu<32, 64, 1, 5, false, false>(prm.layer[1], tile[1], tile[0], red, lane_i, wave & 3, (wave >> 2) * 5, 5);
+        conv_ln_relu<64, 128, 2, 5, false, false>(prm.layer[2], tile[0], tile[1], red, lane_i, (wave & 3) * 2, (wave >> 2) * 5, 5);
+        conv_ln_relu<128, 128, 2, 5, false, true>(prm.layer[3], tile[1], tile[0], red, lane_i, (wave & 3) * 2, (wave >> 2) * 5, 5);
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * P * 128);
         for (int q = tid; q < P * 16; q += THREADS) {
@@ -206,7 +242,7 @@ extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *ob
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
         else cus = 256;
     }
-    const int grid = N < cus ? N : cus;             // one resident workgroup per CU (111 KB of LDS each), persistent over samples
+    const int grid = N < cus ? N : cus;             // one resident 512-thread workgroup per CU (111 KB of LDS each), persistent over samples
     hipLaunchKernelGGL(pol::k_policy_trunk, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
                        reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;

@@ -15,17 +15,17 @@ import torch
 
 from . import _lib as L
 
-_CIN_PAD = (16, 32, 64, 128)
+_CIN_PAD = (32, 32, 64, 128)
 
 
 def _pack_conv(w, cin_pad):
-    """[Cout, Cin, 3, 3] f32 -> bf16 [Cout/32][9*cin_pad/16][64][8] MFMA A fragments (see inversus_hip.h)."""
+    """[Cout, Cin, 3, 3] f32 -> bf16 [Cout/16][9*cin_pad/32][64][8] MFMA A fragments (see inversus_hip.h)."""
     cout, cin = w.shape[:2]
     wp = torch.zeros(cout, 3, 3, cin_pad, dtype=torch.float32, device=w.device)
     wp[..., :cin] = w.permute(0, 2, 3, 1)                       # k = (3*ky + kx) * cin_pad + c
     k = 9 * cin_pad
-    wk = wp.reshape(cout // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4)   # [mt][ks][h][r][8]
-    return wk.reshape(cout // 32, k // 16, 64, 8).contiguous().to(torch.bfloat16)
+    wk = wp.reshape(cout // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4)   # [mt][ks][g][r][8], lane = 16*g + r
+    return wk.reshape(cout // 16, k // 32, 64, 8).contiguous().to(torch.bfloat16)
 
 
 class FusedPolicy:
