@@ -71,11 +71,12 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, const b
     constexpr int KPT = CIN / 32, KS = 9 * KPT;
     const int c16 = lane & 15, kg = lane >> 4;
 
-    int pix[NW], base[NW];
+    int pix[NW], base[NW], tap0[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         pix[i] = (n0 + i) * 16 + c16;
         base[i] = pos_of(min(pix[i], P - 1)) * CSTRIDE;             // columns >= 150 read pixel 149; never stored
+        tap0[i] = base[i] - (PW + 1) * CSTRIDE + 8 * kg;            // fragment address of tap (0,0), channel group 0
     }
 
     f32x4 acc[MW][NW];
@@ -90,21 +91,19 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, const b
     bf16x8 a_cur[MW], a_nxt[MW], b_cur[NW], b_nxt[NW];
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) a_cur[mi] = wp[(size_t)mi * KS * 64];
-    {
-        const int off0 = (-PW - 1) * CSTRIDE + 8 * kg;             // tap (0,0), channel group 0
 #pragma unroll
-        for (int i = 0; i < NW; ++i) b_cur[i] = *reinterpret_cast<const bf16x8 *>(in + base[i] + off0);
-    }
-#pragma unroll 2
+    for (int i = 0; i < NW; ++i) b_cur[i] = *reinterpret_cast<const bf16x8 *>(in + tap0[i]);
+    // fully unrolled: every tap / channel-group offset is an immediate of the ds_read / global_load
+#pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         // fragments of k-step ks+1 (the last prefetch is redundant but in bounds)
         const int ksn = ks + 1 < KS ? ks + 1 : ks;
         const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
-        const int off_n = ((tapn / 3 - 1) * PW + (tapn % 3 - 1)) * CSTRIDE + kcn * 32 + 8 * kg;
+        const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSTRIDE + kcn * 32;
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) a_nxt[mi] = wp[((size_t)mi * KS + ksn) * 64];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) b_nxt[i] = *reinterpret_cast<const bf16x8 *>(in + base[i] + off_n);
+        for (int i = 0; i < NW; ++i) b_nxt[i] = *reinterpret_cast<const bf16x8 *>(in + tap0[i] + off_n);
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
@@ -185,7 +184,8 @@ __global__ __launch_bounds__(THREADS) void k_policy_trunk(inv_policy_params prm,
 {
     __shared__ __attribute__((aligned(16))) bf16 tile[2][NPOS * CSTRIDE];      // 2 x 55 488 B
     __shared__ float red[2 * WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));   // uniform -> tile ownership and weight pointers in SGPRs
 
     // zero both tiles once: the halo and the pad channels stay zero for the life of the block
     for (int i = tid; i < 2 * NPOS * CSTRIDE / 8; i += THREADS) {
