@@ -36,7 +36,7 @@ namespace pol {
 constexpr int H = 10, W = 15, P = H * W;                 // 150 pixels
 constexpr int PW = W + 2, PH = H + 2, NPOS = PW * PH;    // 12 x 17 haloed tile, 204 positions
 constexpr int CSTRIDE = 136;                             // bf16 per position: 128 channels + 8 pad = 272 B
-constexpr int THREADS = 512, WAVES = THREADS / 64;       // 8 waves = 2 per SIMD
+constexpr int THREADS = 256, WAVES = THREADS / 64;       // 4 waves per block, 2 blocks per CU (55 KB LDS each)
 constexpr float LN_EPS = 1e-5f;
 
 typedef __bf16 bf16;
@@ -65,8 +65,7 @@ __device__ __forceinline__ float wave_sum(float x)
 // k-step s+1 are in flight while the MFMAs of k-step s issue (hipcc does not do this on its own: the first
 // version waited on every ds_read and on the L2 load of the next weights inside each k-step).
 template <int CIN, int COUT, int MW, int NW, bool RAGGED, bool RESIDUAL>
-__device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, const bf16 *__restrict__ in, bf16 *__restrict__ out,
-                                             float *red, int lane, int m0, int n0, int ncount)
+__device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *tile, float *red, int lane, int m0, int n0, int ncount)
 {
     constexpr int KPT = CIN / 32, KS = 9 * KPT;
     const int c16 = lane & 15, kg = lane >> 4;
@@ -88,44 +87,34 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, const b
             for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
 
     const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
-    bf16x8 a_cur[MW], a_nxt[MW], b_cur[NW], b_nxt[NW];
+    bf16x8 a_cur[MW], a_nxt[MW], b[NW];
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) a_cur[mi] = wp[(size_t)mi * KS * 64];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) b_cur[i] = *reinterpret_cast<const bf16x8 *>(in + tap0[i]);
-    // fully unrolled: every tap / channel-group offset is an immediate of the ds_read / global_load
+    for (int i = 0; i < NW; ++i) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i]);
+    // fully unrolled: every tap / channel-group offset is an immediate of the ds_read / global_load.
+    // Software pipeline in place: the weight fragments of k-step s+1 are requested at the top of k-step s,
+    // and each activation fragment is re-loaded for k-step s+1 right after its last MFMA of k-step s
+    // (one k-step = MW*NW MFMAs of latency cover, no second fragment buffer).
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        // fragments of k-step ks+1 (the last prefetch is redundant but in bounds)
-        const int ksn = ks + 1 < KS ? ks + 1 : ks;
+        const int ksn = ks + 1 < KS ? ks + 1 : ks;                 // the last prefetch is redundant but in bounds
         const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
         const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSTRIDE + kcn * 32;
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) a_nxt[mi] = wp[((size_t)mi * KS + ksn) * 64];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) b_nxt[i] = *reinterpret_cast<const bf16x8 *>(in + tap0[i] + off_n);
+        for (int i = 0; i < NW; ++i) {
+            if (!RAGGED || i < ncount) {
 #pragma unroll
-        for (int mi = 0; mi < MW; ++mi)
-#pragma unroll
-            for (int i = 0; i < NW; ++i)
-                if (!RAGGED || i < ncount)
-                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[mi], b_cur[i], acc[mi][i], 0, 0, 0);
+                for (int mi = 0; mi < MW; ++mi)
+                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[mi], b[i], acc[mi][i], 0, 0, 0);
+            }
+            b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
+        }
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) a_cur[mi] = a_nxt[mi];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) b_cur[i] = b_nxt[i];
     }
-
-    // LayerNorm affine parameters of this lane's outputs: issue the loads now, they land during the reduction
-    float4 lw[MW][NW], lb[MW][NW];
-#pragma unroll
-    for (int mi = 0; mi < MW; ++mi)
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const size_t o = (size_t)min(pix[i], P - 1) * COUT + (m0 + mi) * 16 + 4 * kg;
-            lw[mi][i] = *reinterpret_cast<const float4 *>(lp.lnw + o);
-            lb[mi][i] = *reinterpret_cast<const float4 *>(lp.lnb + o);
-        }
 
     // bias (+ residual) and the LayerNorm statistics
     float s = 0.0f, ss = 0.0f;
@@ -137,7 +126,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, const b
         for (int i = 0; i < NW; ++i) {
             float x0 = acc[mi][i][0] + bq.x, x1 = acc[mi][i][1] + bq.y, x2 = acc[mi][i][2] + bq.z, x3 = acc[mi][i][3] + bq.w;
             if (RESIDUAL) {
-                const bf16x4 rq = *reinterpret_cast<const bf16x4 *>(in + base[i] + ch0);
+                const bf16x4 rq = *reinterpret_cast<const bf16x4 *>(tile + base[i] + ch0);
                 x0 += (float)rq[0]; x1 += (float)rq[1]; x2 += (float)rq[2]; x3 += (float)rq[3];
             }
             acc[mi][i][0] = x0; acc[mi][i][1] = x1; acc[mi][i][2] = x2; acc[mi][i][3] = x3;
@@ -167,32 +156,38 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, const b
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             if (i < ncount && pix[i] < P) {
+                const size_t po = (size_t)pix[i] * COUT + ch0;
+                const float4 lw = *reinterpret_cast<const float4 *>(lp.lnw + po);
+                const float4 lb = *reinterpret_cast<const float4 *>(lp.lnb + po);
                 bf16x4 o;
-                o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), lw[mi][i].x, lb[mi][i].x), 0.0f);
-                o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), lw[mi][i].y, lb[mi][i].y), 0.0f);
-                o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), lw[mi][i].z, lb[mi][i].z), 0.0f);
-                o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), lw[mi][i].w, lb[mi][i].w), 0.0f);
-                *reinterpret_cast<bf16x4 *>(out + base[i] + ch0) = o;
+                o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), lw.x, lb.x), 0.0f);
+                o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), lw.y, lb.y), 0.0f);
+                o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), lw.z, lb.z), 0.0f);
+                o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), lw.w, lb.w), 0.0f);
+                // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier above,
+                // and the residual read of this lane's own elements precedes this write
+                *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
             }
+            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // at most two tiles' parameter loads in flight (registers)
         }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(THREADS) void k_policy_trunk(inv_policy_params prm, const float *__restrict__ obs,
+__global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params prm, const float *__restrict__ obs,
                                                           bf16 *__restrict__ feat, int N)
 {
-    __shared__ __attribute__((aligned(16))) bf16 tile[2][NPOS * CSTRIDE];      // 2 x 55 488 B
+    __shared__ __attribute__((aligned(16))) bf16 tile[NPOS * CSTRIDE];         // 55 488 B: layers run in place -> 2 blocks / CU
     __shared__ float red[2 * WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));   // uniform -> tile ownership and weight pointers in SGPRs
 
     // zero both tiles once: the halo and the pad channels stay zero for the life of the block
-    for (int i = tid; i < 2 * NPOS * CSTRIDE / 8; i += THREADS) {
+    for (int i = tid; i < NPOS * CSTRIDE / 8; i += THREADS) {
         bf16x8 z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
-        reinterpret_cast<bf16x8 *>(&tile[0][0])[i] = z;
+        reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
     }
     __syncthreads();
 
@@ -207,22 +202,22 @@ __global__ __launch_bounds__(THREADS) void k_policy_trunk(inv_policy_params prm,
         for (int e = tid; e < 32 * P; e += THREADS) {
             const int c = e / P, p = e - c * P;
             const float val = c < 12 ? o[c * P + p] : 0.0f;
-            tile[0][pos_of(p) * CSTRIDE + c] = (bf16)val;
+            tile[pos_of(p) * CSTRIDE + c] = (bf16)val;
         }
         __syncthreads();
-        // tile ownership (8 waves): conv1: 2 row blocks x (3,3,2,2) pixel tiles; conv2: 4 x (5,5); conv3/4: 4 x 2 row blocks x (5,5)
-        {
-            const int g = wave >> 1;
-            conv_ln_relu<32, 32, 1, 3, true, false>(prm.layer[0], tile[0], tile[1], red, lane_i, wave & 1, g < 2 ? g * 3 : 6 + (g - 2) * 2, g < 2 ? 3 : 2);
-        }
-        conv_ln_relu<32, 64, 1, 5, false, false>(prm.layer[1], tile[1], tile[0], red, lane_i, wave & 3, (wave >> 2) * 5, 5);
-        conv_ln_relu<64, 128, 2, 5, false, false>(prm.layer[2], tile[0], tile[1], red, lane_i, (wave & 3) * 2, (wave >> 2) * 5, 5);
-        conv_ln_relu<128, 128, 2, 5, false, true>(prm.layer[3], tile[1], tile[0], red, lane_i, (wave & 3) * 2, (wave >> 2) * 5, 5);
+        // tile ownership (4 waves).  A weight fragment comes from L2 and is reused by NW MFMAs, an activation
+        // fragment comes from LDS and is reused by MW: conv3/4 give every wave 2 row blocks x ALL 10 pixel tiles, so
+        // each weight fragment is fetched exactly once per sample (the L2 -> CU weight stream, ~0.5 MB per sample,
+        // is what bounds this kernel once the matrix pipe is fed: at 8 waves x 5 tiles it was fetched twice).
+        conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5);
+        conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10);
+        conv_ln_relu<64, 128, 2, 10, false, false>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10);
+        conv_ln_relu<128, 128, 2, 10, false, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10);
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * P * 128);
         for (int q = tid; q < P * 16; q += THREADS) {
             const int p = q >> 4, part = q & 15;
-            dst[q] = *reinterpret_cast<const bf16x8 *>(&tile[0][pos_of(p) * CSTRIDE + part * 8]);
+            dst[q] = *reinterpret_cast<const bf16x8 *>(&tile[pos_of(p) * CSTRIDE + part * 8]);
         }
         __syncthreads();
     }
@@ -242,7 +237,7 @@ extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *ob
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
         else cus = 256;
     }
-    const int grid = N < cus ? N : cus;             // one resident 512-thread workgroup per CU (111 KB of LDS each), persistent over samples
+    const int grid = N < 2 * cus ? N : 2 * cus;     // two resident 256-thread workgroups per CU (55 KB of LDS each), persistent over samples
     hipLaunchKernelGGL(pol::k_policy_trunk, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
                        reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
