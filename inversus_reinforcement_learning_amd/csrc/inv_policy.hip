@@ -87,33 +87,35 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
 
     const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
-    bf16x8 a_cur[MW], a_nxt[MW], b[NW];
+    constexpr int AD = 3;                                            // weight fragments are requested AD k-steps ahead (L2 latency)
+    bf16x8 a[AD + 1][MW], b[NW];
 #pragma unroll
-    for (int mi = 0; mi < MW; ++mi) a_cur[mi] = wp[(size_t)mi * KS * 64];
+    for (int d = 0; d < AD; ++d)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) a[d][mi] = wp[((size_t)mi * KS + (d < KS ? d : KS - 1)) * 64];
 #pragma unroll
     for (int i = 0; i < NW; ++i) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i]);
     // fully unrolled: every tap / channel-group offset is an immediate of the ds_read / global_load.
-    // Software pipeline in place: the weight fragments of k-step s+1 are requested at the top of k-step s,
-    // and each activation fragment is re-loaded for k-step s+1 right after its last MFMA of k-step s
-    // (one k-step = MW*NW MFMAs of latency cover, no second fragment buffer).
+    // Software pipeline in place: the weight fragments of k-step s+AD are requested at the top of k-step s
+    // (ring of AD+1 register sets), and each activation fragment is re-loaded for k-step s+1 right after its
+    // last MFMA of k-step s (one k-step = MW*NW MFMAs of latency cover, no second fragment buffer).
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const int ksn = ks + 1 < KS ? ks + 1 : ks;                 // the last prefetch is redundant but in bounds
+        const int ksn = ks + 1 < KS ? ks + 1 : ks;                 // redundant prefetches at the end stay in bounds
+        const int ksa = ks + AD < KS ? ks + AD : KS - 1;
         const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
         const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSTRIDE + kcn * 32;
 #pragma unroll
-        for (int mi = 0; mi < MW; ++mi) a_nxt[mi] = wp[((size_t)mi * KS + ksn) * 64];
+        for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             if (!RAGGED || i < ncount) {
 #pragma unroll
                 for (int mi = 0; mi < MW; ++mi)
-                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[mi], b[i], acc[mi][i], 0, 0, 0);
+                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
             }
             b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
         }
-#pragma unroll
-        for (int mi = 0; mi < MW; ++mi) a_cur[mi] = a_nxt[mi];
     }
 
     // bias (+ residual) and the LayerNorm statistics
@@ -153,22 +155,32 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         const int ch0 = (m0 + mi) * 16 + 4 * kg;
+        // LayerNorm parameter loads are issued five tiles at a time (one L2 round trip per group, 40 registers)
+        constexpr int G = NW < 5 ? NW : 5;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            if (i < ncount && pix[i] < P) {
-                const size_t po = (size_t)pix[i] * COUT + ch0;
-                const float4 lw = *reinterpret_cast<const float4 *>(lp.lnw + po);
-                const float4 lb = *reinterpret_cast<const float4 *>(lp.lnb + po);
-                bf16x4 o;
-                o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), lw.x, lb.x), 0.0f);
-                o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), lw.y, lb.y), 0.0f);
-                o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), lw.z, lb.z), 0.0f);
-                o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), lw.w, lb.w), 0.0f);
-                // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier above,
-                // and the residual read of this lane's own elements precedes this write
-                *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
+        for (int i0 = 0; i0 < NW; i0 += G) {
+            float4 lw[G], lb[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const size_t po = (size_t)min(pix[i0 + j], P - 1) * COUT + ch0;
+                lw[j] = *reinterpret_cast<const float4 *>(lp.lnw + po);
+                lb[j] = *reinterpret_cast<const float4 *>(lp.lnb + po);
             }
-            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // at most two tiles' parameter loads in flight (registers)
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int i = i0 + j;
+                if (i < ncount && pix[i] < P) {
+                    bf16x4 o;
+                    o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), lw[j].x, lb[j].x), 0.0f);
+                    o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), lw[j].y, lb[j].y), 0.0f);
+                    o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), lw[j].z, lb[j].z), 0.0f);
+                    o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), lw[j].w, lb[j].w), 0.0f);
+                    // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
+                    // above, and the residual read of this lane's own elements precedes this write
+                    *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                     // one group's parameter set live at a time
         }
     }
     __syncthreads();
