@@ -210,9 +210,23 @@ class MultiEnvRunner:
         return self._emit(g), self._emit(x)
 
     def step(self, action_ids, opponent_policy=None):
-        """-> ((grid, extra), rewards f32[N], dones bool[N], infos list[dict])."""
+        """-> ((grid, extra), rewards f32[N], dones bool[N], infos).
+
+        output="numpy": host arrays and a list of N dicts, exactly like the reference.
+        output="torch": device tensors; `infos` is an InfoBatch (device tensors, `infos[i]` builds the
+        reference's dict on demand) and nothing synchronises unless an episode ended this step."""
         a2 = self._opponent_actions(opponent_policy)
         res = self.batch.step(action_ids, a2, auto_reset=self.auto_reset)
+        if self.output == "torch":
+            infos = InfoBatch(res)
+            if bool(res.done.any()):                                      # one scalar D2H; stats only for finished envs
+                idx = res.done.nonzero().flatten().tolist()
+                for i in idx:
+                    d = infos[i]
+                    self.episode_returns[i], self.episode_lengths[i] = d["episode_return"], d["episode_steps"]
+                    self.episode_wins[i] += int(d["win"])
+                    self.episode_losses[i] += int(d["lose"])
+            return (res.obs, res.extra), res.reward, res.done.bool(), infos
         self.batch.check()                                                # ValueError on a bad action id
         fl = res.info_flags.cpu().numpy()
         st = res.episode_steps.cpu().numpy()
@@ -224,9 +238,26 @@ class MultiEnvRunner:
             self.episode_lengths[i] = infos[i]["episode_steps"]
             self.episode_wins[i] += int(infos[i]["win"])
             self.episode_losses[i] += int(infos[i]["lose"])
-        if self.output == "numpy":
-            return (res.obs.cpu().numpy(), res.extra.cpu().numpy()), res.reward.cpu().numpy(), dones, infos
-        return (res.obs, res.extra), res.reward, res.done.bool(), infos
+        return (res.obs.cpu().numpy(), res.extra.cpu().numpy()), res.reward.cpu().numpy(), dones, infos
+
+
+class InfoBatch:
+    """Per-step info of a device batch: the reference's dict keys as device tensors; `infos[i]` -> dict."""
+
+    def __init__(self, res):
+        self.info_flags, self.episode_steps, self.episode_return = res.info_flags, res.episode_steps, res.episode_return
+
+    def __len__(self):
+        return int(self.info_flags.shape[0])
+
+    def flag(self, bit):
+        return (self.info_flags & bit) != 0
+
+    def __getitem__(self, i):
+        f = int(self.info_flags[i])
+        return {"landed_hit": bool(f & L.INV_INFO_LANDED_HIT), "got_hit": bool(f & L.INV_INFO_GOT_HIT),
+                "win": bool(f & L.INV_INFO_WIN), "lose": bool(f & L.INV_INFO_LOSE),
+                "episode_steps": int(self.episode_steps[i]), "episode_return": float(self.episode_return[i])}
 
 
 class SingleInversusRLEnv:

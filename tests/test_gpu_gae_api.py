@@ -158,3 +158,25 @@ def test_single_env_and_build_observation():
     g, x = env.reset(seed=99)
     o2 = orc.OracleEnv(15, 10, seed=99)
     assert bits_eq(g, o2.build_observation(0)[0])
+
+
+def test_runner_torch_output_mode():
+    """output="torch": device tensors, lazy infos, auto-reset fused; same numbers as the numpy mode."""
+    import torch
+    from inversus_reinforcement_learning_amd.env_wrappers import MultiEnvRunner
+    n = 128
+    rt = MultiEnvRunner(n, "dummy", "hard", max_episode_steps=15, seed=7, output="torch", auto_reset=True, opp_seed=3)
+    rn = MultiEnvRunner(n, "dummy", "hard", max_episode_steps=15, seed=7, output="numpy", auto_reset=True, opp_seed=3)
+    gt, xt = rt.reset(); gn, xn = rn.reset()
+    assert isinstance(gt, torch.Tensor) and gt.is_cuda and bits_eq(gt.cpu().numpy(), gn)
+    rng = np.random.RandomState(0)
+    for t in range(40):
+        a = rng.randint(0, 13, n)
+        (gt, xt), rw_t, dn_t, inf_t = rt.step(torch.from_numpy(a).cuda())
+        (gn, xn), rw_n, dn_n, inf_n = rn.step(a)
+        assert bits_eq(gt.cpu().numpy(), gn) and bits_eq(rw_t.cpu().numpy(), rw_n)
+        assert np.array_equal(dn_t.cpu().numpy(), dn_n)
+        for i in np.nonzero(dn_n)[0][:3]:
+            assert inf_t[int(i)] == inf_n[int(i)]
+    assert rt.episode_lengths == rn.episode_lengths and rt.episode_wins == rn.episode_wins
+    rt.batch.check()
