@@ -1,39 +1,24 @@
-"""Enums and the Action record of the reference's public API (inversus/game_types.py:8-49),
-kept so that `discrete_to_action` and state views return the same vocabulary.  The integer
-codes are the SoA encodings of include/inversus_hip.h."""
-from dataclasses import dataclass
+"""The public vocabulary of the reference's API (inversus/game_types.py:8-71) -- enum members and
+record fields that `discrete_to_action` and the state views hand back -- tied to the integer codes of
+the device SoA (include/inversus_hip.h).  Names and values match the reference so that callers'
+comparisons (`action.type == ActionType.MOVE`, `tile == TileColor.WHITE`) keep working."""
+from dataclasses import dataclass, field, make_dataclass
 from enum import Enum
 from typing import Optional
 
+TileColor = Enum("TileColor", {"BLACK": "black", "WHITE": "white"})            # grid bit 0 / 1
+Direction = Enum("Direction", {"UP": "up", "DOWN": "down", "LEFT": "left", "RIGHT": "right"})
+ActionType = Enum("ActionType", {"MOVE": "move", "SHOOT": "shoot", "CHARGE_SHOOT": "charge_shoot", "NONE": "none"})
+PlayerId = Enum("PlayerId", {"P1": 1, "P2": 2})
+for _e in (TileColor, Direction, ActionType, PlayerId):
+    _e.__module__ = __name__
 
-class TileColor(Enum):
-    BLACK = "black"      # grid bit 0
-    WHITE = "white"      # grid bit 1
-
-
-class Direction(Enum):
-    UP = "up"
-    DOWN = "down"
-    LEFT = "left"
-    RIGHT = "right"
-
-
-class ActionType(Enum):
-    MOVE = "move"
-    SHOOT = "shoot"
-    CHARGE_SHOOT = "charge_shoot"
-    NONE = "none"
-
-
-class PlayerId(Enum):
-    P1 = 1
-    P2 = 2
-
-
-#: observation-channel order of directions (env_wrappers.py:216-221) == device `dir` code
+#: device `dir` code -> Direction, in observation-channel order (env_wrappers.py:216-221)
 DIR_BY_CODE = (Direction.UP, Direction.RIGHT, Direction.DOWN, Direction.LEFT)
 CODE_BY_DIR = {d: i for i, d in enumerate(DIR_BY_CODE)}
+#: (action_id + 3) >> 2 -> ActionType
 TYPE_BY_CODE = (ActionType.NONE, ActionType.MOVE, ActionType.SHOOT, ActionType.CHARGE_SHOOT)
+_DIRECTED = frozenset(TYPE_BY_CODE[1:])
 
 
 @dataclass
@@ -42,28 +27,16 @@ class Action:
     direction: Optional[Direction] = None
 
     def __post_init__(self):
-        needs_dir = self.type in (ActionType.MOVE, ActionType.SHOOT, ActionType.CHARGE_SHOOT)
-        if needs_dir and self.direction is None:
+        # same consistency rule and messages as the reference (game_types.py:42-49)
+        if self.type in _DIRECTED and self.direction is None:
             raise ValueError(f"Action type {self.type} requires a direction")
-        if self.type == ActionType.NONE and self.direction is not None:
+        if self.type is ActionType.NONE and self.direction is not None:
             raise ValueError("Action type NONE must have direction=None")
 
 
-@dataclass
-class PlayerState:
-    player_id: PlayerId
-    x: int
-    y: int
-    color: TileColor
-    ammo: int
-    max_ammo: int
-    reload_counter: int
-    alive: bool = True
-
-
-@dataclass
-class Bullet:
-    x: int
-    y: int
-    dir: Direction
-    owner: PlayerId
+PlayerState = make_dataclass("PlayerState", [("player_id", PlayerId), ("x", int), ("y", int), ("color", TileColor),
+                                             ("ammo", int), ("max_ammo", int), ("reload_counter", int),
+                                             ("alive", bool, field(default=True))])
+Bullet = make_dataclass("Bullet", [("x", int), ("y", int), ("dir", Direction), ("owner", PlayerId)])
+for _c in (PlayerState, Bullet):
+    _c.__module__ = __name__
