@@ -71,6 +71,93 @@ def cpu_baseline(difficulty, budget_s=12.0):
             "sample": f"{steps} vector steps x {n} envs, vs_dummy_{difficulty}, C oracle (OpenMP over envs), obs rendered"}
 
 
+def side_measurements(torch, np, n):
+    """Secondary numbers of the same build for the record (never `value`): other configurations of the
+    step kernel, the GAE scan, the fused policy trunk and the policy-in-the-loop self-play collector.
+    Every entry is best-effort: a failure is reported as a string and never breaks the JSON line."""
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch, gae
+
+    def timed(fn, reps, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3          # us
+
+    out = {}
+
+    def guard(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as exc:                          # pragma: no cover
+            out[name] = f"failed: {type(exc).__name__}: {exc}"
+
+    def step_cfg(W_, H_, opponent, difficulty, obs_p2, selfplay_bytes):
+        def run():
+            b = DeviceEnvBatch(n, W_, H_, K, opponent=opponent, difficulty=difficulty, opp_seed=1)
+            b.seed(np.arange(n, dtype=np.int64)); b.reset()
+            o = b._alloc_out((), True, obs_p2, False, None)
+            acts = torch.stack([b.uniform_actions(5, t) for t in range(64)])
+            a2 = torch.stack([b.uniform_actions(6, t) for t in range(64)]) if opponent == "selfplay" else None
+            k = [0]
+            steppers = [b.make_stepper(o, None if a2 is None else a2[j], auto_reset=True) for j in range(64)] if a2 is not None \
+                else [b.make_stepper(o, None, auto_reset=True)] * 64
+
+            def f():
+                j = k[0] % 64
+                k[0] += 1
+                steppers[j](acts[j].data_ptr())
+            us = timed(f, 128, warm=64)
+            by = algorithmic_bytes_per_env_step(W_, H_, K, selfplay=selfplay_bytes) * n
+            return {"us_per_vector_step": round(us, 2), "env_steps_per_s": round(n / us * 1e6), "GBps": round(by / us / 1e3, 1)}
+        return run
+
+    guard("step vs_dummy_hard 15x10", step_cfg(15, 10, "dummy", "hard", False, False))
+    guard("step selfplay 15x10 (P1+P2 obs)", step_cfg(15, 10, "selfplay", "easy", True, True))
+    guard("step vs_dummy_hard 32x32 K=16 (C5)", step_cfg(32, 32, "dummy", "hard", False, False))
+
+    def gae_cfg():
+        T = 128
+        r = torch.randn(T, n, device="cuda"); v = torch.randn(T, n, device="cuda")
+        d = (torch.rand(T, n, device="cuda") < 0.03).to(torch.uint8)
+        us = timed(lambda: gae(r, v, d, layout="per_env"), 20)
+        return {"T": T, "us_incl_wrapper": round(us, 2), "GBps": round(17 * T * n / us / 1e3, 1)}
+    guard("gae per_env T=128", gae_cfg)
+
+    def policy_cfg():
+        from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+        from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+        from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+        from inversus_reinforcement_learning_amd.training import RolloutCollector
+        torch.manual_seed(0)
+        pol = InversusCNNPolicy(12, H, W, 4).cuda().eval()
+        fused = FusedPolicy(pol)
+        g = (torch.rand(n, 12, H, W, device="cuda") < 0.2).float()
+        x = torch.rand(n, 4, device="cuda")
+        res = {"fused_trunk_ms": round(timed(lambda: fused.features(g), 5) / 1e3, 3),
+               "fused_forward_ms": round(timed(lambda: fused(g, x), 5) / 1e3, 3)}
+        res["fused_trunk_TFLOPs"] = round(72.9e6 * n / (res["fused_trunk_ms"] * 1e-3) / 1e12, 1)
+        with torch.no_grad():
+            res["torch_f32_forward_ms"] = round(timed(lambda: pol(g, x), 3, warm=1) / 1e3, 3)
+        b = DeviceEnvBatch(n, opponent="selfplay")
+        b.seed(np.arange(n, dtype=np.int64)); b.reset()
+        agent = PPOAgent(pol, fused_act=True)
+        opp = FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval())
+        col = RolloutCollector(b, agent, opp)
+        col.collect(2); agent.reset_buffers(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); col.collect(8); torch.cuda.synchronize()
+        res["selfplay_collector_env_steps_per_s"] = round(8 * n / (time.perf_counter() - t0))
+        agent.reset_buffers()
+        return res
+    guard("policy in the loop (selfplay, fused bf16 trunk, 2 forwards/step)", policy_cfg)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +165,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--difficulty", default="easy", choices=["easy", "hard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--share-device", action="store_true",
@@ -178,6 +266,10 @@ def main():
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.difficulty)
+        if not args.no_extras and world == 1:
+            del b, out, a1_all
+            torch.cuda.empty_cache()
+            res["extras"] = side_measurements(torch, np, n)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
