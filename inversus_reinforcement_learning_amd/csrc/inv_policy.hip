@@ -46,6 +46,28 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ int pos_of(int p) { return (p / W + 1) * PW + (p % W) + 1; }
 
+// Diagnostic build only (-DINV_POLICY_STAMPS, never the shipped library): per-phase cycle shares of wave 0,
+// accumulated into a buffer of its own that no kernel code reads (cdna_hip_programming.md, "In-kernel stamps").
+#ifdef INV_POLICY_STAMPS
+__device__ unsigned long long g_stamps[16];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        const unsigned long long now_ = stamp_now();                                         \
+        if (threadIdx.x == 0) atomicAdd(&g_stamps[slot], now_ - stamp_prev);                 \
+        stamp_prev = now_;                                                                   \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ float wave_sum(float x)
 {
 #pragma unroll
@@ -65,7 +87,8 @@ __device__ __forceinline__ float wave_sum(float x)
 // k-step s+1 are in flight while the MFMAs of k-step s issue (hipcc does not do this on its own: the first
 // version waited on every ds_read and on the L2 load of the next weights inside each k-step).
 template <int CIN, int COUT, int MW, int NW, bool RAGGED, bool RESIDUAL>
-__device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *tile, float *red, int lane, int m0, int n0, int ncount)
+__device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *tile, float *red, int lane, int m0, int n0, int ncount,
+                                             unsigned long long &stamp_prev, int layer)
 {
     constexpr int KPT = CIN / 32, KS = 9 * KPT;
     const int c16 = lane & 15, kg = lane >> 4;
@@ -118,6 +141,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         }
     }
 
+    STAMP(1 + layer);                                                // GEMM
     // bias (+ residual) and the LayerNorm statistics
     float s = 0.0f, ss = 0.0f;
 #pragma unroll
@@ -143,6 +167,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     const int wave = threadIdx.x >> 6;
     if (lane == 0) { red[wave] = s; red[WAVES + wave] = ss; }
     __syncthreads();
+    STAMP(5 + layer);                                                // statistics + barrier
     const float cnt = (float)(COUT * P);
     float S = 0.0f, SS = 0.0f;
 #pragma unroll
@@ -184,6 +209,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         }
     }
     __syncthreads();
+    STAMP(9 + layer);                                                // epilogue + barrier
 }
 
 __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params prm, const float *__restrict__ obs,
@@ -203,28 +229,55 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
     }
     __syncthreads();
 
+    unsigned long long stamp_prev = 0;
+#ifdef INV_POLICY_STAMPS
+    stamp_prev = stamp_now();
+#endif
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         // Per-lane addresses (LDS fragment bases, LayerNorm parameter pointers of all four layers: ~160
         // registers) are invariant over this loop; hipcc hoists them out and then spills them to scratch
         // around the MFMA loops.  Laundering the lane id makes them cheap per-sample recomputations instead.
         int lane_i = lane;
         asm volatile("" : "+v"(lane_i));
-        // observation f32 [12][150] -> tile 0, channels-last, 32 channels (12..31 zero: the k-step is 32 wide)
-        const float *o = obs + (size_t)n * 12 * P;
-        for (int e = tid; e < 32 * P; e += THREADS) {
-            const int c = e / P, p = e - c * P;
-            const float val = c < 12 ? o[c * P + p] : 0.0f;
-            tile[pos_of(p) * CSTRIDE + c] = (bf16)val;
+        // observation f32 [12][150] -> tile, channels-last, 32 channels (12..31 zero: the k-step is 32 wide).
+        // Both float4 loads of a thread are issued before anything is converted (one HBM round trip, not 19).
+        {
+            const float4 *o4 = reinterpret_cast<const float4 *>(obs + (size_t)n * 12 * P);     // 450 float4 per sample
+            const int q0 = tid, q1 = tid + THREADS;
+            const float4 v0 = o4[q0];
+            float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q1 < 12 * P / 4) v1 = o4[q1];
+            // pad channels 12..31 of every pixel: 40 B at byte offset 24 of the position = 5 x 8 B
+            for (int z = tid; z < P * 5; z += THREADS) {
+                const int p = z / 5, part = z - p * 5;
+                bf16x4 zz;
+                zz[0] = zz[1] = zz[2] = zz[3] = (bf16)0.0f;
+                *reinterpret_cast<bf16x4 *>(&tile[pos_of(p) * CSTRIDE + 12 + part * 4]) = zz;
+            }
+            const float e0[4] = { v0.x, v0.y, v0.z, v0.w }, e1[4] = { v1.x, v1.y, v1.z, v1.w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * q0 + j, c = e / P, p = e - c * P;
+                tile[pos_of(p) * CSTRIDE + c] = (bf16)e0[j];
+            }
+            if (q1 < 12 * P / 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * q1 + j, c = e / P, p = e - c * P;
+                    tile[pos_of(p) * CSTRIDE + c] = (bf16)e1[j];
+                }
+            }
         }
         __syncthreads();
+        STAMP(0);                                                    // observation load + conversion
         // tile ownership (4 waves).  A weight fragment comes from L2 and is reused by NW MFMAs, an activation
         // fragment comes from LDS and is reused by MW: conv3/4 give every wave 2 row blocks x ALL 10 pixel tiles, so
         // each weight fragment is fetched exactly once per sample (the L2 -> CU weight stream, ~0.5 MB per sample,
         // is what bounds this kernel once the matrix pipe is fed: at 8 waves x 5 tiles it was fetched twice).
-        conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5);
-        conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10);
-        conv_ln_relu<64, 128, 2, 10, false, false>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10);
-        conv_ln_relu<128, 128, 2, 10, false, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10);
+        conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
+        conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
+        conv_ln_relu<64, 128, 2, 10, false, false>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2);
+        conv_ln_relu<128, 128, 2, 10, false, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3);
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * P * 128);
         for (int q = tid; q < P * 16; q += THREADS) {
@@ -232,10 +285,23 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
             dst[q] = *reinterpret_cast<const bf16x8 *>(&tile[pos_of(p) * CSTRIDE + part * 8]);
         }
         __syncthreads();
+        STAMP(13);                                                   // feature write-out
     }
 }
 
 }  // namespace pol
+
+#ifdef INV_POLICY_STAMPS
+extern "C" int inv_policy_debug_stamps(unsigned long long *out16_host, int reset)
+{
+    if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(pol::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return INV_ERR_HIP;
+    if (reset) {
+        unsigned long long z[16] = { 0 };
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pol::g_stamps), z, sizeof z) != hipSuccess) return INV_ERR_HIP;
+    }
+    return INV_OK;
+}
+#endif
 
 extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *obs, void *feat_bf16, int32_t N, void *stream)
 {
