@@ -21,12 +21,10 @@ There is no CPU fallback: without the HIP library and a GPU the constructors rai
 import os
 
 import numpy as np
-import torch
 
 from . import _lib as L
 from .device_env import DeviceEnvBatch
-from .vocab import (Action, ActionType, Bullet, Direction, PlayerId, PlayerState, TileColor,
-                    DIR_BY_CODE, TYPE_BY_CODE)
+from .vocab import Action, ActionType, Bullet, PlayerId, PlayerState, TileColor, DIR_BY_CODE, TYPE_BY_CODE
 
 MAX_AMMO = 6
 

@@ -14,7 +14,6 @@ GAE layout:
 Deviations from the reference that cannot be bit-matched in parallel (global-RNG consumers):
 Categorical sampling and the minibatch permutation use torch's device generator.
 """
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.optim as optim
