@@ -309,6 +309,54 @@ def gen_policy():
                         n_params=sum(p.numel() for p in pol.parameters()))
 
 
+# --------------------------------------------------------------------------- G7
+def gen_arbitrary(n_cases=1500, W=15, H=10):
+    """One wrapper step from ARBITRARY states, set the way the reference's own tests set them
+    (env._set_tile, env.player1.x = ..., env.bullets = [Bullet(...)]): many bullets on one tile with mixed
+    owners, players on top of each other / on their own colour, any ammo / reload / alive combination."""
+    from inversus.game_types import Bullet
+    rng = np.random.RandomState(77)
+    DIRS = [Direction.UP, Direction.RIGHT, Direction.DOWN, Direction.LEFT]
+    keys = ("grid", "players", "nbullets", "bullets", "steps", "epret", "prev", "a1", "a2",
+            "o_grid", "o_players", "o_nbullets", "o_bullets", "o_obs", "o_extra", "o_obs_p2", "o_reward", "o_done", "o_info", "o_steps", "o_epret")
+    rec = {k: [] for k in keys}
+    for c in range(n_cases):
+        w = ew.SingleInversusRLEnv(opponent_type="selfplay", max_episode_steps=50, seed=c)
+        env = w.env
+        dens = rng.choice([0.05, 0.5, 0.95])
+        for y in range(H):
+            for x in range(W):
+                env._set_tile(x, y, TileColor.WHITE if rng.random_sample() < dens else TileColor.BLACK)
+        for p in (env.player1, env.player2):
+            p.x, p.y = int(rng.randint(0, W)), int(rng.randint(0, H))
+            p.ammo, p.reload_counter, p.alive = int(rng.randint(0, 7)), int(rng.randint(0, 30)), bool(rng.random_sample() < 0.85)
+        if rng.random_sample() < 0.1:
+            env.player2.x, env.player2.y = env.player1.x, env.player1.y
+        nb = int(rng.randint(0, 11))
+        cx, cy = rng.randint(0, W), rng.randint(0, H)
+        env.bullets = [Bullet(x=int(np.clip(cx + rng.randint(-2, 3), 0, W - 1)), y=int(np.clip(cy + rng.randint(-2, 3), 0, H - 1)),
+                              dir=DIRS[rng.randint(0, 4)], owner=PlayerId.P1 if rng.randint(0, 2) == 0 else PlayerId.P2)
+                       for _ in range(nb)]
+        w.step_count = int(rng.randint(0, 52))
+        w.episode_return = float(rng.randn())
+        w.prev_p1_alive, w.prev_p2_alive = bool(rng.random_sample() < 0.9), bool(rng.random_sample() < 0.9)
+        a1, a2 = int(rng.randint(0, 13)), int(rng.randint(0, 13))
+        rec["grid"].append(grid_words(env)); rec["players"].append(player_rows(env)); rec["nbullets"].append(nb)
+        rec["bullets"].append(bullet_words(env)); rec["steps"].append(w.step_count); rec["epret"].append(w.episode_return)
+        rec["prev"].append([w.prev_p1_alive, w.prev_p2_alive]); rec["a1"].append(a1); rec["a2"].append(a2)
+        (g, x), r, d, info = w.step(a1, opponent_policy=lambda obs, a=a2: a)
+        g2, _ = ew.build_observation(env, PlayerId.P2)
+        rec["o_grid"].append(grid_words(env)); rec["o_players"].append(player_rows(env)); rec["o_nbullets"].append(len(env.bullets))
+        rec["o_bullets"].append(bullet_words(env)); rec["o_obs"].append(obs_bits(g)); rec["o_extra"].append(x)
+        rec["o_obs_p2"].append(obs_bits(g2)); rec["o_reward"].append(r); rec["o_done"].append(d)
+        rec["o_info"].append([info["landed_hit"], info["got_hit"], info["win"], info["lose"]])
+        rec["o_steps"].append(info["episode_steps"]); rec["o_epret"].append(info["episode_return"])
+    arr = {k: np.array(v) for k, v in rec.items()}
+    arr["o_reward"] = arr["o_reward"].astype(np.float64); arr["epret"] = arr["epret"].astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, "g7_arbitrary_15x10.npz"), W=W, H=H, max_steps=50, **arr)
+    print("g7: cases", n_cases, "dones", int(arr["o_done"].sum()), "max bullets after", int(arr["o_nbullets"].max()))
+
+
 def main():
     gen_spawn(15, 10)
     gen_spawn(32, 32)
@@ -324,6 +372,7 @@ def main():
     gen_gae()
     gen_dummy()
     gen_policy()
+    gen_arbitrary()
 
 
 if __name__ == "__main__":

@@ -425,3 +425,78 @@ def test_step_is_hip_graph_capturable(torch_cuda):
     se, sg = eager.get_state(), graphed.get_state()
     for k in se:
         assert bits_eq(se[k], sg[k]), k
+
+
+@pytest.mark.parametrize("W,H,K", [(15, 10, 16), (32, 32, 16), (6, 5, 24)])
+def test_arbitrary_states_vs_oracle(torch_cuda, W, H, K):
+    """One full step from ARBITRARY (not just reachable) states: random grids, players anywhere (also on top of
+    each other / on their own colour), any ammo / reload / alive / prev_alive combination, up to K-6 bullets with
+    random positions, directions and owners (many on the same tile), random step counters around the timeout."""
+    from oracle import oracle as orc
+    from oracle.oracle import pack_bullet
+    n = 2048
+    rng = np.random.RandomState(W * 100 + K)
+    GW = (W * H + 31) // 32
+    b = make(n, W, H, max_bullets=K, opponent="selfplay", max_episode_steps=50)
+    b.seed(np.arange(n, dtype=np.int64)); b.reset()
+    ob = orc.OracleBatch(n, W, H, max_episode_steps=50)
+    ob.seed_reset(np.arange(n, dtype=np.int64))
+    for rep in range(6):
+        dens = rng.choice([0.05, 0.5, 0.95], size=(n, 1))
+        bits = (rng.random_sample((n, GW * 32)) < dens).astype(np.uint32)
+        bits[:, W * H:] = 0
+        grid = (bits.reshape(n, GW, 32) << np.arange(32, dtype=np.uint32)).sum(axis=2).astype(np.uint32)
+        players = np.zeros((n, 2, 5), np.int32)
+        players[:, :, 0] = rng.randint(0, W, (n, 2)); players[:, :, 1] = rng.randint(0, H, (n, 2))
+        same = rng.random_sample(n) < 0.1
+        players[same, 1, :2] = players[same, 0, :2]
+        players[:, :, 2] = rng.randint(0, 7, (n, 2)); players[:, :, 3] = rng.randint(0, 30, (n, 2))
+        players[:, :, 4] = (rng.random_sample((n, 2)) < 0.85)
+        nb = rng.randint(0, K - 5, n).astype(np.int32)
+        cx, cy = rng.randint(0, W, n), rng.randint(0, H, n)                     # cluster centre: forces shared target tiles
+        bx = np.clip(cx[:, None] + rng.randint(-2, 3, (n, K)), 0, W - 1)
+        by = np.clip(cy[:, None] + rng.randint(-2, 3, (n, K)), 0, H - 1)
+        bd, bo = rng.randint(0, 4, (n, K)), rng.randint(0, 2, (n, K))
+        bullets = (bx | (by << 6) | (bd << 12) | (bo << 14)).astype(np.uint16)
+        bullets[np.arange(K)[None, :] >= nb[:, None]] = 0
+        steps = rng.randint(0, 52, n).astype(np.int32)
+        epret = rng.randn(n)
+        prev = (rng.random_sample((n, 2)) < 0.9).astype(np.uint8)
+        b.set_state(grid=grid, players=players, nbullets=nb, bullets=bullets, step_count=steps, episode_return=epret, prev_alive=prev)
+        for i in range(n):
+            e = ob.env(i)
+            e.set_grid_bits(grid[i])
+            for pid in range(2):
+                e.set_player(pid, *[int(v) for v in players[i, pid]])
+            e.set_bullets([(int(bx[i, j]), int(by[i, j]), int(bd[i, j]), int(bo[i, j])) for j in range(nb[i])])
+            e.s.step_count = int(steps[i]); e.s.episode_return = float(epret[i])
+            e.s.prev_alive[0], e.s.prev_alive[1] = int(prev[i, 0]), int(prev[i, 1])
+        a1 = rng.randint(0, 13, n).astype(np.uint8); a2 = rng.randint(0, 13, n).astype(np.uint8)
+        r = b.step(a1, a2, auto_reset=(rep % 2 == 0), obs_p2=True, reward64=True)
+        o_obs, o_extra, _, o_r64, o_done, o_info = ob.step(a1, a2, auto_reset=(rep % 2 == 0), nthreads=8)
+        _compare_step(b, ob, r, o_obs, o_extra, o_r64, o_done, o_info, rep)
+        g2, x2 = ob.observe(1)
+        assert bits_eq(r.obs_p2.cpu().numpy(), g2) and bits_eq(r.extra_p2.cpu().numpy(), x2)
+    b.check()
+
+
+def test_arbitrary_states_golden(torch_cuda):
+    """G7: one step from 1 500 arbitrary states set the way the reference's tests poke them, against the
+    reference's own outputs (all cases as one device batch)."""
+    g = load("g7_arbitrary_15x10.npz")
+    n = len(g["a1"])
+    b = make(n, 15, 10, opponent="selfplay", max_episode_steps=int(g["max_steps"]))
+    b.seed(np.arange(n, dtype=np.int64)); b.reset()
+    b.set_state(grid=g["grid"], players=g["players"], nbullets=g["nbullets"].astype(np.int32), bullets=g["bullets"],
+                step_count=g["steps"].astype(np.int32), episode_return=g["epret"], prev_alive=g["prev"].astype(np.uint8))
+    r = b.step(g["a1"].astype(np.uint8), g["a2"].astype(np.uint8), obs_p2=True, reward64=True)
+    s = b.get_state()
+    assert np.array_equal(s["grid"], g["o_grid"]) and np.array_equal(s["players"], g["o_players"])
+    assert np.array_equal(s["nbullets"], g["o_nbullets"]) and np.array_equal(s["bullets"], g["o_bullets"])
+    assert np.array_equal(obs_bits(r.obs), g["o_obs"]) and np.array_equal(obs_bits(r.obs_p2), g["o_obs_p2"])
+    assert bits_eq(r.extra.cpu().numpy(), g["o_extra"])
+    assert bits_eq(r.reward64.cpu().numpy(), g["o_reward"]) and np.array_equal(r.done.cpu().numpy(), g["o_done"].astype(np.uint8))
+    want = g["o_info"].astype(np.uint8)
+    assert np.array_equal(r.info_flags.cpu().numpy(), want[:, 0] | (want[:, 1] << 1) | (want[:, 2] << 2) | (want[:, 3] << 3))
+    assert np.array_equal(r.episode_steps.cpu().numpy(), g["o_steps"]) and bits_eq(r.episode_return.cpu().numpy(), g["o_epret"].astype(np.float64))
+    b.check()

@@ -180,3 +180,29 @@ def test_dummy_device_statistics():
         a = e.dummy_device(False, 77, 6)
         moves += (a != 0)
     assert moves / n < 0.004
+
+
+# ------------------------------------------------------------------ G7 arbitrary (unreachable) states
+def test_arbitrary_states_golden():
+    g = load("g7_arbitrary_15x10.npz")
+    W, H = int(g["W"]), int(g["H"])
+    n = len(g["a1"])
+    e = orc.OracleEnv(W, H, seed=0, max_episode_steps=int(g["max_steps"]))
+    for c in range(n):
+        e.set_grid_bits(g["grid"][c])
+        for pid in range(2):
+            e.set_player(pid, *[int(v) for v in g["players"][c, pid]])
+        e.set_bullets([orc.unpack_bullet(w) for w in g["bullets"][c, :int(g["nbullets"][c])]])
+        e.s.step_count = int(g["steps"][c]); e.s.episode_return = float(g["epret"][c])
+        e.s.prev_alive[0], e.s.prev_alive[1] = int(g["prev"][c, 0]), int(g["prev"][c, 1])
+        r, d, info = e.step(int(g["a1"][c]), int(g["a2"][c]))
+        assert np.array_equal(e.grid_bits(), g["o_grid"][c]), c
+        assert np.array_equal(e.players(), g["o_players"][c]), c
+        assert e.s.nb == g["o_nbullets"][c] and np.array_equal(e.bullets_packed(K), g["o_bullets"][c]), c
+        o, x = e.build_observation(0)
+        assert np.array_equal(_bits(o), g["o_obs"][c]) and np.array_equal(x.view(np.uint32), g["o_extra"][c].view(np.uint32)), c
+        assert np.array_equal(_bits(e.build_observation(1)[0]), g["o_obs_p2"][c]), c
+        assert np.float64(r).view(np.uint64) == g["o_reward"][c].view(np.uint64) and d == bool(g["o_done"][c]), c
+        assert (info.landed_hit, info.got_hit, info.win, info.lose) == tuple(g["o_info"][c]), c
+        assert info.episode_steps == g["o_steps"][c]
+        assert np.float64(info.episode_return).view(np.uint64) == np.float64(g["o_epret"][c]).view(np.uint64), c
