@@ -103,3 +103,11 @@ def test_training_loop_with_fused_actor(tmp_path):
     res = training.train_selfplay(num_envs=64, total_steps=64 * 128, log_dir=str(tmp_path / "fused"), seed=4, verbose=False,
                                   agent_kwargs=dict(batch_size=2048, epochs=1, fused_act=True))
     assert res["steps"] == 64 * 128 and np.isfinite(res["policy_loss"]) and np.isfinite(res["entropy"])
+
+
+def test_update_with_bf16_autocast():
+    import torch
+    from inversus_reinforcement_learning_amd import training
+    res = training.train_vs_dummy(num_envs=64, total_steps=64 * 128, log_dir=None, opponent_difficulty="hard", seed=9, verbose=False,
+                                  agent_kwargs=dict(batch_size=2048, epochs=1, update_autocast=torch.bfloat16))
+    assert np.isfinite(res["policy_loss"]) and np.isfinite(res["value_loss"]) and res["entropy"] > 2.0
