@@ -15,6 +15,23 @@ using namespace inv;
 
 // =================================================================== kernels
 
+// Diagnostic build only (-DINV_STEP_STAMPS, never the shipped library): per-phase cycle sums over all waves,
+// kept apart for waves that reset this step ([8..15]) and waves that do not ([0..7]); slot 7 / 15 = wave count.
+#ifdef INV_STEP_STAMPS
+__device__ unsigned long long g_step_stamps[16];
+__device__ __forceinline__ unsigned long long step_stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define SSTAMP(slot) do { const unsigned long long n_ = step_stamp_now(); st_acc[slot] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define SSTAMP(slot) do { } while (0)
+#endif
+
 // LDS slice of a wave: [nibble table 64][grid GW][bullet slots K][scratch >= 624]
 template <class D>
 struct WaveLds {
@@ -37,17 +54,22 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
     const int env = blockIdx.x * kWavesPerBlock + wv;
     const int N = a.d.N;
     if (env >= N) return;                           // wave-uniform; no block barriers below
-    if (a.mask && rfl((int)a.mask[env]) == 0) return;
+    if (a.mask && sload_u8(a.mask, (size_t)env) == 0u) return;
     const D d(a.d);
     const WaveLds<D> L(d, lds, wv);
     uint32_t *g = L.g;
     const float4 *tab = reinterpret_cast<const float4 *>(L.tabw);
 
     // issue the action loads of the first step together with the state loads
-    uint32_t act1v = a.a1[env], act2v = a.a2 ? (uint32_t)a.a2[env] : 0u;
+    uint32_t act1v = sload_u8(a.a1, (size_t)env), act2v = a.a2 ? sload_u8(a.a2, (size_t)env) : 0u;
     init_nibble_table(reinterpret_cast<float *>(L.tabw), lane);
+#ifdef INV_STEP_STAMPS
+    unsigned long long st_acc[7] = { 0, 0, 0, 0, 0, 0, 0 }, st_prev = step_stamp_now();
+    int st_reset = 0;
+#endif
     Env e;
     load_env(d, a.s, env, lane, g, e);
+    SSTAMP(0);                                      // launch -> state loaded
     uint32_t err = 0u;
     const size_t obs_stride = (size_t)12 * d.WH;
     const bool full = (a.flags & INV_STEP_DEFAULT) == INV_STEP_DEFAULT;
@@ -68,15 +90,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
             o.reward = ka->o.reward; o.reward64 = ka->o.reward64; o.done = ka->o.done; o.info_flags = ka->o.info_flags;
             o.episode_steps = ka->o.episode_steps; o.episode_return = ka->o.episode_return;
         }
-        if (t > 0) { act1v = a.a1[idx]; act2v = a.a2 ? (uint32_t)a.a2[idx] : 0u; }
+        if (t > 0) { act1v = sload_u8(a.a1, idx); act2v = a.a2 ? sload_u8(a.a2, idx) : 0u; }
         const int act1 = rfl((int)act1v);
         int act2;
         if (a.a2) {
             act2 = rfl((int)act2v);
         } else {
-            act2 = rfl(dummy_action(d, g, e, a.hard, a.opp_seed, a.env_offset + (uint32_t)env, e.opp_ctr));
+            act2 = rfl(dummy_action(d, g, lane, e, a.hard, a.opp_seed, a.env_offset + (uint32_t)env, e.opp_ctr));
             e.opp_ctr += 1u;
         }
+        SSTAMP(1);                                  // actions / dummy opponent
         double reward = 0.0;
         int done = 0;
         uint32_t info = 0u;
@@ -93,43 +116,40 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
             if (full || (a.flags & INV_PHASE_BULLETS)) tile_diff = update_bullets(d, g, L.slots, lane, e);   // :531
 
             if (full || (a.flags & INV_PHASE_WRAPPER)) {      // env_wrappers.py:333-442, f64 adds in the reference's order
+                // Branch-free: every term the reference skips is added as +0.0 instead (exact: the running sum is
+                // never -0.0), so the sequence of roundings is the reference's; selects instead of a dozen uniform
+                // branches (A/B on one box: neutral for speed, kept for the straight-line code).
                 e.step_count += 1;
                 const Player &p1 = e.p[0], &p2 = e.p[1];
-                if (tile_diff > 0) reward += (double)tile_diff * 0.01;
-                if (e.prev2 && !p2.alive) { reward += 1.0; info |= INV_INFO_LANDED_HIT; }
-                if (e.prev1 && !p1.alive) { reward -= 0.01; info |= INV_INFO_GOT_HIT; }
-                if (p1.alive && p1.ammo == 0) reward -= 0.001;
-                if (p1.alive && p2.alive) {
-                    const int dist = abs(p1.x - p2.x) + abs(p1.y - p2.y);
-                    reward += (SINGLE ? a.s.prox : ka->s.prox)[dist];
-                    const bool aligned = p1.x == p2.x || p1.y == p2.y;
-                    if (aligned) reward += 0.002;
-                    if (act1 >= 5 && aligned && p1.ammo > 0) {
-                        const int shot = (act1 - 1) & 3;
-                        bool aiming = false;
-                        if (p1.x == p2.x) aiming = (p1.y < p2.y && shot == 2) || (p1.y > p2.y && shot == 0);
-                        else aiming = (p1.x < p2.x && shot == 1) || (p1.x > p2.x && shot == 3);
-                        if (aiming) reward += 0.05;
-                    }
-                }
-                const bool over = !(p1.alive && p2.alive);
-                if (over) {
-                    done = 1;
-                    if (p1.alive && !p2.alive) { reward += 10.0; info |= INV_INFO_WIN; }
-                    else if (p2.alive && !p1.alive) { reward -= 0.1; info |= INV_INFO_LOSE; }
-                } else {
-                    reward -= 0.001;
-                }
-                e.prev1 = p1.alive;
-                e.prev2 = p2.alive;
-                if (e.step_count >= a.d.max_steps) {
-                    done = 1;
-                    if (!over) reward -= 2.0;
-                }
+                const int al1 = p1.alive, al2 = p2.alive, both = al1 & al2, over = both ^ 1;
+                const int landed = e.prev2 & (al2 ^ 1), got = e.prev1 & (al1 ^ 1);
+                const int win = al1 & (al2 ^ 1), lose = al2 & (al1 ^ 1);
+                const int xeq = p1.x == p2.x, yeq = p1.y == p2.y, aligned = xeq | yeq;
+                const int dist = abs(p1.x - p2.x) + abs(p1.y - p2.y);
+                const int shot = (act1 - 1) & 3;
+                const int aim_v = ((p1.y < p2.y) & (shot == 2)) | ((p1.y > p2.y) & (shot == 0));
+                const int aim_h = ((p1.x < p2.x) & (shot == 1)) | ((p1.x > p2.x) & (shot == 3));
+                const int aiming = both & aligned & (act1 >= 5) & (p1.ammo > 0) & (xeq ? aim_v : aim_h);
+                const int timeout = e.step_count >= a.d.max_steps;
+                const double prox = sload_f64(SINGLE ? a.s.prox : ka->s.prox, dist);        // dist <= W + H - 2: always in the table
+                reward += tile_diff > 0 ? (double)tile_diff * 0.01 : 0.0;                    // :349-354
+                reward += landed ? 1.0 : 0.0;                                                // :357-362
+                reward += got ? -0.01 : 0.0;                                                 // :364-369
+                reward += (al1 & (p1.ammo == 0)) ? -0.001 : 0.0;                             // :372-373
+                reward += both ? prox : 0.0;                                                 // :378-382
+                reward += (both & aligned) ? 0.002 : 0.0;                                    // :385-387
+                reward += aiming ? 0.05 : 0.0;                                               // :391-405
+                reward += over ? (win ? 10.0 : (lose ? -0.1 : 0.0)) : -0.001;                // :408-427
+                reward += (timeout & both) ? -2.0 : 0.0;                                     // :434-438
+                done = over | timeout;
+                info = (uint32_t)(landed * INV_INFO_LANDED_HIT | got * INV_INFO_GOT_HIT | (over & win) * INV_INFO_WIN | (over & lose) * INV_INFO_LOSE);
+                e.prev1 = al1;
+                e.prev2 = al2;
                 e.ep_ret += reward;
             }
         }
 
+        SSTAMP(2);                                  // tick + reward
         if (lane == 0) {
             if (o.reward) o.reward[idx] = (float)reward;
             if (o.reward64) o.reward64[idx] = reward;
@@ -139,19 +159,33 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
             if (o.episode_return) o.episode_return[idx] = e.ep_ret;
         }
 
+        SSTAMP(3);                                  // scalar outputs
         if (done && (a.flags & INV_STEP_AUTO_RESET)) {                                            // training.py:148-151
             State rs = a.s;
             if (!SINGLE) rs.mt = ka->s.mt;
             reset_env(d, rs, env, lane, g, L.scr, e);
+#ifdef INV_STEP_STAMPS
+            st_reset = 1;
+#endif
         }
+        SSTAMP(4);                                  // reset
 
         if (o.obs) render_obs(d, g, L.scr, tab, lane, 0, e, o.obs + idx * obs_stride, o.extra ? o.extra + idx * 4 : nullptr);
         if (o.obs_p2) render_obs(d, g, L.scr, tab, lane, 1, e, o.obs_p2 + idx * obs_stride, o.extra_p2 ? o.extra_p2 + idx * 4 : nullptr);
     }
 
+    SSTAMP(5);                                      // observation render(s)
     if (SINGLE) {
         store_env(d, a.s, env, lane, g, e);
         if (err && lane == 0) atomicOr(a.s.err, err);
+#ifdef INV_STEP_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SSTAMP(6);                                  // state store, all stores drained
+        if (lane == 0) {
+            for (int q = 0; q < 7; ++q) atomicAdd(&g_step_stamps[st_reset * 8 + q], st_acc[q]);
+            atomicAdd(&g_step_stamps[st_reset * 8 + 7], 1ull);
+        }
+#endif
     } else {
         typedef const volatile StepArgs __attribute__((address_space(4))) *KernargPtr;
         const KernargPtr ka = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -356,6 +390,18 @@ static int fail(int code, const char *fmt, ...)
 static inline int env_blocks(int n) { return (n + kWavesPerBlock - 1) / kWavesPerBlock; }
 
 extern "C" {
+
+#ifdef INV_STEP_STAMPS
+int inv_step_debug_stamps(unsigned long long *out16_host, int reset)
+{
+    if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_step_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return INV_ERR_HIP;
+    if (reset) {
+        unsigned long long z[16] = { 0 };
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_step_stamps), z, sizeof z) != hipSuccess) return INV_ERR_HIP;
+    }
+    return INV_OK;
+}
+#endif
 
 const char *inv_last_error(void) { return g_err; }
 int inv_abi_version(void) { return INV_ABI_VERSION; }

@@ -105,6 +105,21 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Wave-uniform reads of read-only inputs through the SCALAR cache (s_load) instead of a vector load + readfirstlane:
+// they do not queue behind the CU's vector stores of the observation stream.  Safe for data no kernel on the
+// stream writes while this kernel runs (actions, masks, the proximity table).
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+typedef const __attribute__((address_space(4))) double *const_f64_ptr;
+
+__device__ __forceinline__ uint32_t sload_u8(const uint8_t *p, size_t idx)
+{
+    const uintptr_t a = (uintptr_t)p + idx;
+    const uint32_t w = *(const_u32_ptr)(a & ~(uintptr_t)3);        // the aligned word that holds the byte
+    return (w >> (8u * (uint32_t)(a & 3u))) & 0xffu;
+}
+
+__device__ __forceinline__ double sload_f64(const double *p, int idx) { return ((const_f64_ptr)p)[idx]; }
+
 __device__ __forceinline__ uint32_t tile_bit(const uint32_t *g, int pos) { return (g[pos >> 5] >> (pos & 31)) & 1u; }
 
 __device__ __forceinline__ uint32_t pack_bullet(int x, int y, int dir, int owner)
@@ -455,7 +470,7 @@ __device__ __forceinline__ uint32_t dummy_word(uint32_t key, uint32_t ctr, uint3
 }
 
 template <class D>
-__device__ inline int dummy_action(const D &d, const uint32_t *g, const Env &e, int hard, uint32_t seed, uint32_t genv, uint32_t ctr)
+__device__ inline int dummy_action(const D &d, const uint32_t *g, int lane, const Env &e, int hard, uint32_t seed, uint32_t genv, uint32_t ctr)
 {
     const Player &p1 = e.p[0], &p2 = e.p[1];
     if (!p2.alive) return 0;                                               // :77-78
@@ -470,12 +485,16 @@ __device__ inline int dummy_action(const D &d, const uint32_t *g, const Env &e, 
         }
     }
 
-    // walkable-for-P2 mask over directions (in bounds and tile != WHITE), :116-118 etc.
-    uint32_t walk = 0u;
-#pragma unroll
-    for (int dir = 0; dir < 4; ++dir) {
-        const int nx = p2.x + dir_dx(dir), ny = p2.y + dir_dy(dir);
-        if ((unsigned)nx < (unsigned)d.W && (unsigned)ny < (unsigned)d.H && rfl(tile_bit(g, ny * d.W + nx)) == 0u) walk |= 1u << dir;
+    // walkable-for-P2 mask over directions (in bounds and tile != WHITE), :116-118 etc.: lane d < 4 tests
+    // direction d and one ballot collects the mask (instead of four scalar bounds-check + LDS-read +
+    // readfirstlane sequences)
+    uint32_t walk;
+    {
+        const int dl = lane & 3;
+        const int nx = p2.x + dir_dx(dl), ny = p2.y + dir_dy(dl);
+        const bool inb = (unsigned)nx < (unsigned)d.W && (unsigned)ny < (unsigned)d.H;
+        const bool ok = lane < 4 && inb && tile_bit(g, inb ? ny * d.W + nx : 0) == 0u;
+        walk = (uint32_t)__ballot(ok) & 15u;
     }
     uint32_t dirs = 0u | (2u << 4) | (3u << 8) | (1u << 12);               // [UP, DOWN, LEFT, RIGHT], :104
     if (hard && dummy_word(key, ctr, 1u) <= 214748364u) {                  // :105-119, random_move_prob 0.05
