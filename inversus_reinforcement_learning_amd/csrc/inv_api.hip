@@ -15,10 +15,11 @@ using namespace inv;
 
 // =================================================================== kernels
 
-// Diagnostic build only (-DINV_STEP_STAMPS, never the shipped library): per-phase cycle sums over all waves,
-// kept apart for waves that reset this step ([8..15]) and waves that do not ([0..7]); slot 7 / 15 = wave count.
+// Diagnostic build only (-DINV_STEP_STAMPS, never the shipped library): per-wave phase cycles of the LAST launch,
+// one 8-word record per env (7 phases + a "this wave reset" flag), written once per wave to a buffer of its own.
 #ifdef INV_STEP_STAMPS
-__device__ unsigned long long g_step_stamps[16];
+constexpr int kStampEnvs = 16384;
+__device__ unsigned long long g_step_stamps[kStampEnvs * 8];
 __device__ __forceinline__ unsigned long long step_stamp_now()
 {
     unsigned long long t;
@@ -181,9 +182,9 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
 #ifdef INV_STEP_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SSTAMP(6);                                  // state store, all stores drained
-        if (lane == 0) {
-            for (int q = 0; q < 7; ++q) atomicAdd(&g_step_stamps[st_reset * 8 + q], st_acc[q]);
-            atomicAdd(&g_step_stamps[st_reset * 8 + 7], 1ull);
+        if (lane == 0 && env < kStampEnvs) {
+            for (int q = 0; q < 7; ++q) g_step_stamps[env * 8 + q] = st_acc[q];
+            g_step_stamps[env * 8 + 7] = (unsigned long long)st_reset;
         }
 #endif
     } else {
@@ -392,14 +393,9 @@ static inline int env_blocks(int n) { return (n + kWavesPerBlock - 1) / kWavesPe
 extern "C" {
 
 #ifdef INV_STEP_STAMPS
-int inv_step_debug_stamps(unsigned long long *out16_host, int reset)
+int inv_step_debug_stamps(unsigned long long *out_host /* [16384][8] */)
 {
-    if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_step_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return INV_ERR_HIP;
-    if (reset) {
-        unsigned long long z[16] = { 0 };
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_step_stamps), z, sizeof z) != hipSuccess) return INV_ERR_HIP;
-    }
-    return INV_OK;
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_step_stamps), sizeof(unsigned long long) * kStampEnvs * 8) == hipSuccess ? INV_OK : INV_ERR_HIP;
 }
 #endif
 

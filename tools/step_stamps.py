@@ -8,20 +8,23 @@ import numpy as np, torch
 from inversus_reinforcement_learning_amd import _lib
 from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
 lib = _lib.load()
-lib.inv_step_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+lib.inv_step_debug_stamps.argtypes = [C.c_void_p]
 n = 16384
 names = ["load state", "actions/dummy", "tick+reward", "scalar outputs", "reset", "render", "store+drain"]
 for diff in ("easy", "hard"):
     b = DeviceEnvBatch(n, opponent="dummy", difficulty=diff, opp_seed=1)
     b.seed(np.arange(n, dtype=np.int64)); b.reset()
     out = b._alloc_out((), True, False, False, None)
-    for t in range(150): b.step(b.uniform_actions(1, t), None, auto_reset=True, out=out)
-    torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 16)(); lib.inv_step_debug_stamps(buf, 1)
-    for t in range(150, 200): b.step(b.uniform_actions(1, t), None, auto_reset=True, out=out)
-    torch.cuda.synchronize(); lib.inv_step_debug_stamps(buf, 0)
-    v = list(buf)
-    for tag, off in (("no reset", 0), ("reset", 8)):
-        cnt = v[off + 7]
-        if cnt:
-            print(diff, tag, "waves", cnt, {nm: round(v[off + i] / cnt) for i, nm in enumerate(names)}, "total", round(sum(v[off:off + 7]) / cnt))
+    acc = np.zeros((2, 8)); cnt = np.zeros(2)
+    for t in range(230):
+        b.step(b.uniform_actions(1, t), None, auto_reset=True, out=out)
+        if t >= 200:
+            torch.cuda.synchronize()
+            buf = np.zeros((n, 8), np.uint64)
+            lib.inv_step_debug_stamps(buf.ctypes.data_as(C.c_void_p))
+            for r in (0, 1):
+                m = buf[:, 7] == r
+                acc[r] += buf[m].astype(np.float64).sum(0); cnt[r] += m.sum()
+    for r, tag in ((0, "no reset"), (1, "reset")):
+        if cnt[r]:
+            print(diff, tag, "waves/launch", round(cnt[r] / 30, 1), {nm: int(acc[r, i] / cnt[r]) for i, nm in enumerate(names)}, "total cycles", int(acc[r, :7].sum() / cnt[r]))
