@@ -24,10 +24,12 @@ def init_from_env(backend=None):
         return world()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        # INVERSUS_DIST_BACKEND=gloo + INVERSUS_SHARE_DEVICE=1 rehearse the multi-rank path on a 1-GPU box
+        backend = os.environ.get("INVERSUS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    lr = 0 if os.environ.get("INVERSUS_SHARE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
         torch.cuda.set_device(lr)
+    if backend == "nccl":
         dist.init_process_group(backend, device_id=torch.device("cuda", lr))
     else:
         dist.init_process_group(backend)

@@ -159,7 +159,8 @@ def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, w
     batch.check()
     if log_dir and rank == 0:
         torch.save(policy.state_dict(), os.path.join(log_dir, "policy_final.pt"))
-    return {"steps": step_count, "episodes": episode_count, "seconds": time.time() - t0, **stats}
+    digest = float(sum(p.detach().double().abs().sum() for p in policy.parameters()))   # same on every rank if in sync
+    return {"steps": step_count, "episodes": episode_count, "seconds": time.time() - t0, "param_abs_sum": digest, **stats}
 
 
 def train_vs_dummy(num_envs=1, total_steps=500_000, log_dir="runs/inversus_vs_dummy", opponent_difficulty="easy",

@@ -111,3 +111,33 @@ def test_update_with_bf16_autocast():
     res = training.train_vs_dummy(num_envs=64, total_steps=64 * 128, log_dir=None, opponent_difficulty="hard", seed=9, verbose=False,
                                   agent_kwargs=dict(batch_size=2048, epochs=1, update_autocast=torch.bfloat16))
     assert np.isfinite(res["policy_loss"]) and np.isfinite(res["value_loss"]) and res["entropy"] > 2.0
+
+
+def test_two_rank_training_rehearsal():
+    """The multi-rank training path (env shards by global index, flat gradient all-reduce, global advantage
+    statistics) with two processes sharing the one GPU of the test box over gloo: both ranks finish the same
+    number of steps and hold identical parameters."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), INVERSUS_DIST_BACKEND="gloo", INVERSUS_SHARE_DEVICE="1", PYTHONPATH=root)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "_dist_train_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "TRAIN_OK" in out, f"rank {rank}:\\n{out[-3000:]}"
