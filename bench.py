@@ -53,22 +53,36 @@ def cpu_baseline(difficulty, budget_s=12.0):
     import numpy as np
     from oracle import oracle as orc
     cores = min(os.cpu_count() or 1, 16)
-    n = NUM_ENVS
-    ob = orc.OracleBatch(n, W, H)
-    ob.seed_reset(np.arange(n, dtype=np.int64))
     L = orc.lib()
     hard = difficulty == "hard"
-    acts = [np.array([L.orc_uniform_action(1234, i, t) for i in range(n)], np.uint8) for t in range(4)]
-    ob.step(acts[0], None, hard=hard, opp_seed=1, nthreads=cores)          # warm-up
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        ob.step(acts[steps % 4], None, hard=hard, opp_seed=1, nthreads=cores)
-        steps += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or steps >= 4000:
-            break
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} vector steps x {n} envs, vs_dummy_{difficulty}, C oracle (OpenMP over envs), obs rendered"}
+
+    def run(n, threads, budget):
+        ob = orc.OracleBatch(n, W, H)
+        ob.seed_reset(np.arange(n, dtype=np.int64))
+        acts = [np.array([L.orc_uniform_action(1234, i, t) for i in range(n)], np.uint8) for t in range(4)]
+        ob.step(acts[0], None, hard=hard, opp_seed=1, nthreads=threads)          # warm-up
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            ob.step(acts[steps % 4], None, hard=hard, opp_seed=1, nthreads=threads)
+            steps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or steps >= 20000:
+                break
+        return n * steps / dt, steps
+
+    v, steps = run(NUM_ENVS, cores, budget_s)
+    v1, _ = run(NUM_ENVS, 1, 3.0)
+    v4, _ = run(4, 1, 1.0)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} vector steps x {NUM_ENVS} envs, vs_dummy_{difficulty}, C oracle (OpenMP over envs), obs rendered",
+            "one_core_env_steps_per_s": round(v1), "n4_one_core_env_steps_per_s": round(v4),
+            "host": {"cpu_model": model, "nproc": os.cpu_count()}}
 
 
 def side_measurements(torch, np, n):
@@ -161,8 +175,8 @@ def side_measurements(torch, np, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--difficulty", default="easy", choices=["easy", "hard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
