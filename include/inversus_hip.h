@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define INV_ABI_VERSION 1
+#define INV_ABI_VERSION 2
 
 typedef enum {
     INV_OK = 0,
@@ -61,6 +61,11 @@ enum {
     INV_PHASE_BULLETS = 4u,       /* core.py:531 */
     INV_PHASE_WRAPPER = 8u,       /* step_count, reward, done, info (env_wrappers.py:318-442) */
     INV_STEP_AUTO_RESET = 16u,    /* training.py:148-151: reset done envs, emit the reset obs */
+    INV_STEP_OBS_BITS = 32u,      /* obs / obs_p2 receive the PACKED observation instead of f32 planes: they point at
+                                     uint32_t[N][inv_obs_words_per_env] and bit c*H*W + y*W + x of an env's bitstring is set
+                                     iff build_observation's grid[c][y][x] == 1.0 (env_wrappers.py:196-235; every entry of
+                                     that array is 0.0 or 1.0, so the bitstring is lossless; pad bits are 0).  32x fewer
+                                     bytes for on-device consumers: inv_policy_trunk_bits, rollout buffers, inv_unpack_obs */
     INV_STEP_DEFAULT  = 15u
 };
 
@@ -86,7 +91,7 @@ typedef struct {
 
 /* Optional per-step outputs; any pointer may be NULL. */
 typedef struct {
-    float   *obs, *extra;         /* P1 observation of the state the caller continues from */
+    float   *obs, *extra;         /* P1 observation of the state the caller continues from (see INV_STEP_OBS_BITS) */
     float   *obs_p2, *extra_p2;   /* same state from P2's perspective (self-play opponent input) */
     float   *reward;              /* f32(f64 reward), env_wrappers.py:525 */
     double  *reward64;            /* the f64 sum itself (parity checks) */
@@ -120,6 +125,7 @@ int  inv_get_config(const inv_handle *h, inv_config *cfg);
 /* bytes of one env's obs / words per grid, for sizing caller buffers */
 int64_t inv_obs_floats_per_env(const inv_handle *h);   /* 12*H*W */
 int32_t inv_grid_words(const inv_handle *h);           /* GW */
+int32_t inv_obs_words_per_env(const inv_handle *h);    /* ceil(12*H*W / 32): u32 words of one packed observation */
 
 /* random.Random(seed) per env (core.py:41,58): CPython's init_by_array on the 32-bit
  * words of abs(seed).  seeds_host: N int64 in HOST memory.  Also zeroes opp_ctr. */
@@ -145,6 +151,11 @@ int  inv_step_masked(inv_handle *h, const uint8_t *mask, const uint8_t *a1, cons
 
 /* build_observation(env, player) (env_wrappers.py:173-245); player 0 = P1, 1 = P2. */
 int  inv_render_obs(inv_handle *h, int32_t player, float *obs, float *extra, void *stream);
+/* Same observation as a packed bitstring, bits: uint32_t[N][inv_obs_words_per_env] (see INV_STEP_OBS_BITS). */
+int  inv_render_obs_bits(inv_handle *h, int32_t player, uint32_t *bits, float *extra, void *stream);
+/* Packed -> f32 planes for n observations of floats_per_env = 12*H*W floats each (words per env =
+ * ceil(floats_per_env / 32)); needs no handle, so a learner can expand minibatches of stored rollouts. */
+int  inv_unpack_obs(const uint32_t *bits, int64_t n, int32_t floats_per_env, float *obs, void *stream);
 
 /* State poke / dump, the SoA form of the reference tests' direct field access
  * (tests/test_bullet_collision.py etc. set env.bullets / env.player1.x / _set_tile). */
@@ -168,7 +179,7 @@ int  inv_uniform_actions(uint8_t *a, int32_t n, uint32_t seed, int64_t env_offse
 /* T vector steps in ONE launch with pre-supplied actions a1[T][N] (a2[T][N] or NULL),
  * writing the rollout buffers obs[T][N][12][H][W] ... -- the persistent multi-step form
  * of inv_step (always auto-resets).  Outputs as inv_step_out with a leading T dim. */
-int  inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2,
+int  inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2, uint32_t flags /* 0 or INV_STEP_OBS_BITS */,
                  const inv_step_out *out, void *stream);
 
 /* ---- fused policy trunk -------------------------------------------------
@@ -184,6 +195,9 @@ int  inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2,
 typedef struct { const void *w; const float *bias; const float *lnw; const float *lnb; } inv_policy_layer;
 typedef struct { inv_policy_layer layer[4]; } inv_policy_params;
 int  inv_policy_trunk(const inv_policy_params *params, const float *obs, void *feat_bf16, int32_t N, void *stream);
+/* Same trunk reading packed observations, bits: uint32_t[N][57] (INV_STEP_OBS_BITS layout of the 15 x 10 board):
+ * 228 B instead of 7 200 B per sample, the next sample's words are fetched while the current one computes. */
+int  inv_policy_trunk_bits(const inv_policy_params *params, const uint32_t *bits, void *feat_bf16, int32_t N, void *stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ INV_ERR_BAD_ACTION, INV_ERR_BULLET_OVERFLOW, INV_ERR_NO_OPPONENT = -4, -5, -6
 INV_OPP_EXTERNAL, INV_OPP_DUMMY = 0, 1
 INV_EASY, INV_HARD = 0, 1
 INV_PHASE_ACTIONS, INV_PHASE_RELOAD, INV_PHASE_BULLETS, INV_PHASE_WRAPPER = 1, 2, 4, 8
-INV_STEP_AUTO_RESET, INV_STEP_DEFAULT = 16, 15
+INV_STEP_AUTO_RESET, INV_STEP_OBS_BITS, INV_STEP_DEFAULT = 16, 32, 15
 INV_INFO_LANDED_HIT, INV_INFO_GOT_HIT, INV_INFO_WIN, INV_INFO_LOSE = 1, 2, 4, 8
 INV_GAE_REFERENCE_FLAT, INV_GAE_PER_ENV = 0, 1
 
@@ -57,19 +57,23 @@ SIGNATURES = {
     "inv_get_config": (C.c_int, [_V, P(InvConfig)]),
     "inv_obs_floats_per_env": (C.c_int64, [_V]),
     "inv_grid_words": (C.c_int32, [_V]),
+    "inv_obs_words_per_env": (C.c_int32, [_V]),
     "inv_seed": (C.c_int, [_V, _V, _V]),
     "inv_seed_masked": (C.c_int, [_V, _V, _V, _V]),
     "inv_reset": (C.c_int, [_V, _V, _V]),
     "inv_step": (C.c_int, [_V, _V, _V, C.c_uint32, P(InvStepOut), _V]),
     "inv_step_masked": (C.c_int, [_V, _V, _V, _V, C.c_uint32, P(InvStepOut), _V]),
     "inv_render_obs": (C.c_int, [_V, C.c_int32, _V, _V, _V]),
+    "inv_render_obs_bits": (C.c_int, [_V, C.c_int32, _V, _V, _V]),
+    "inv_unpack_obs": (C.c_int, [_V, C.c_int64, C.c_int32, _V, _V]),
     "inv_get_state": (C.c_int, [_V, P(InvStateView), _V]),
     "inv_set_state": (C.c_int, [_V, P(InvStateView), _V]),
     "inv_check": (C.c_int, [_V, _V]),
     "inv_gae": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_float, C.c_float, _V, C.c_int32, _V, _V, _V]),
     "inv_uniform_actions": (C.c_int, [_V, C.c_int32, C.c_uint32, C.c_int64, C.c_uint32, _V]),
-    "inv_rollout": (C.c_int, [_V, C.c_int32, _V, _V, P(InvStepOut), _V]),
+    "inv_rollout": (C.c_int, [_V, C.c_int32, _V, _V, C.c_uint32, P(InvStepOut), _V]),
     "inv_policy_trunk": (C.c_int, [P(InvPolicyParams), _V, _V, C.c_int32, _V]),
+    "inv_policy_trunk_bits": (C.c_int, [P(InvPolicyParams), _V, _V, C.c_int32, _V]),
 }
 
 _lib = None

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
     load_env(d, a.s, env, lane, g, e);
     SSTAMP(0);                                      // launch -> state loaded
     uint32_t err = 0u;
-    const size_t obs_stride = (size_t)12 * d.WH;
+    const bool obits = (a.flags & INV_STEP_OBS_BITS) != 0u;       // obs / obs_p2 receive the packed bitstring
+    const size_t obs_stride = obits ? (size_t)d.OW : (size_t)12 * d.WH;   // in 4-byte elements either way
     const bool full = (a.flags & INV_STEP_DEFAULT) == INV_STEP_DEFAULT;
 
     const int T = SINGLE ? 1 : a.T;
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
         }
         SSTAMP(4);                                  // reset
 
-        if (o.obs) render_obs(d, g, L.scr, tab, lane, 0, e, o.obs + idx * obs_stride, o.extra ? o.extra + idx * 4 : nullptr);
-        if (o.obs_p2) render_obs(d, g, L.scr, tab, lane, 1, e, o.obs_p2 + idx * obs_stride, o.extra_p2 ? o.extra_p2 + idx * 4 : nullptr);
+        if (o.obs) render_obs(d, g, L.scr, tab, lane, 0, e, o.obs + idx * obs_stride, o.extra ? o.extra + idx * 4 : nullptr, obits);
+        if (o.obs_p2) render_obs(d, g, L.scr, tab, lane, 1, e, o.obs_p2 + idx * obs_stride, o.extra_p2 ? o.extra_p2 + idx * 4 : nullptr, obits);
     }
 
     SSTAMP(5);                                      // observation render(s)
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_reset(Dims dd, State
 }
 
 template <class D>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims dd, State s, int player, float *obs, float *extra)
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims dd, State s, int player, float *obs, float *extra, int as_bits)
 {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (kWave - 1), wv = rfl((int)(threadIdx.x >> 6));
@@ -226,7 +227,20 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims dd, Stat
     Env e;
     load_env(d, s, env, lane, L.g, e);
     render_obs(d, L.g, L.scr, reinterpret_cast<const float4 *>(L.tabw), lane, player, e,
-               obs + (size_t)env * 12 * d.WH, extra ? extra + (size_t)env * 4 : nullptr);
+               obs + (size_t)env * (as_bits ? (size_t)d.OW : (size_t)12 * d.WH), extra ? extra + (size_t)env * 4 : nullptr, as_bits != 0);
+}
+
+// Packed observation bitstring -> f32 planes: float4 q of env i = nibble (q & 7) of word q >> 3 (the same
+// expansion render_obs applies in LDS), for the consumers that want f32 (the PPO update's minibatches).
+__global__ __launch_bounds__(256) void k_unpack_obs(const uint32_t *__restrict__ bits, long long total, int f4_per_env, int words_per_env,
+                                                    float4 *__restrict__ obs)
+{
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    const long long env = j / f4_per_env;
+    const int q = (int)(j - env * f4_per_env);
+    const uint32_t nib = (bits[env * words_per_env + (q >> 3)] >> ((q & 7) * 4)) & 15u;
+    obs[j] = make_float4((nib & 1u) ? 1.0f : 0.0f, (nib & 2u) ? 1.0f : 0.0f, (nib & 4u) ? 1.0f : 0.0f, (nib & 8u) ? 1.0f : 0.0f);
 }
 
 // Pick the dims policy: the two configurations of BASELINE.json get fully folded code.
@@ -474,6 +488,7 @@ int inv_get_config(const inv_handle *h, inv_config *cfg)
 
 int64_t inv_obs_floats_per_env(const inv_handle *h) { return h ? (int64_t)12 * h->d.WH : 0; }
 int32_t inv_grid_words(const inv_handle *h) { return h ? h->d.GW : 0; }
+int32_t inv_obs_words_per_env(const inv_handle *h) { return h ? h->d.OW : 0; }
 
 int inv_seed_masked(inv_handle *h, const int64_t *seeds_host, const uint8_t *mask_host, void *stream)
 {
@@ -544,18 +559,42 @@ int inv_step_masked(inv_handle *h, const uint8_t *mask, const uint8_t *a1, const
     return launch_step(h, 1, mask, a1, a2, flags, out, stream);
 }
 
-int inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2, const inv_step_out *out, void *stream)
+int inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2, uint32_t flags, const inv_step_out *out, void *stream)
 {
     if (T < 1) return fail(INV_ERR_BAD_ARG, "inv_rollout: T must be >= 1");
-    return launch_step(h, T, nullptr, a1, a2, INV_STEP_DEFAULT | INV_STEP_AUTO_RESET, out, stream);
+    if (flags & ~(uint32_t)INV_STEP_OBS_BITS) return fail(INV_ERR_BAD_ARG, "inv_rollout: only INV_STEP_OBS_BITS may be passed");
+    return launch_step(h, T, nullptr, a1, a2, INV_STEP_DEFAULT | INV_STEP_AUTO_RESET | flags, out, stream);
 }
 
-int inv_render_obs(inv_handle *h, int32_t player, float *obs, float *extra, void *stream)
+static int launch_render(inv_handle *h, int32_t player, float *obs, float *extra, int as_bits, void *stream)
 {
     if (!h || !obs) return fail(INV_ERR_BAD_ARG, "inv_render_obs: NULL argument");
     if (player != 0 && player != 1) return fail(INV_ERR_BAD_ARG, "Invalid player ID: %d", player);   // core.py:198
     INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL(k_render<DT>, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes,
-                                               (hipStream_t)stream, h->d, h->s, player, obs, extra));
+                                               (hipStream_t)stream, h->d, h->s, player, obs, extra, as_bits));
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+int inv_render_obs(inv_handle *h, int32_t player, float *obs, float *extra, void *stream)
+{
+    return launch_render(h, player, obs, extra, 0, stream);
+}
+
+int inv_render_obs_bits(inv_handle *h, int32_t player, uint32_t *bits, float *extra, void *stream)
+{
+    return launch_render(h, player, reinterpret_cast<float *>(bits), extra, 1, stream);
+}
+
+int inv_unpack_obs(const uint32_t *bits, int64_t n, int32_t floats_per_env, float *obs, void *stream)
+{
+    if (!bits || !obs || n < 0 || floats_per_env <= 0 || (floats_per_env & 3)) return fail(INV_ERR_BAD_ARG, "inv_unpack_obs: bad argument");
+    if (n == 0) return INV_OK;
+    const long long total = (long long)n * (floats_per_env / 4);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(INV_ERR_BAD_ARG, "inv_unpack_obs: n too large for one launch");
+    hipLaunchKernelGGL(k_unpack_obs, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bits, total, floats_per_env / 4,
+                       (floats_per_env + 31) / 32, reinterpret_cast<float4 *>(obs));
     HIP_TRY(hipGetLastError());
     return INV_OK;
 }

@@ -548,7 +548,7 @@ __device__ __forceinline__ void init_nibble_table(float *tab, int lane)
 // consecutive 16 B, 1 KiB per wave store instruction.
 template <class D>
 __device__ inline void render_obs(const D &d, const uint32_t *g, uint32_t *ob, const float4 *tab, int lane, int pid,
-                                  const Env &e, float *__restrict__ obs_env, float *__restrict__ extra_env)
+                                  const Env &e, float *__restrict__ obs_env, float *__restrict__ extra_env, bool as_bits = false)
 {
     const int WH = d.WH;
     const uint32_t lastmask = (WH & 31) ? ((1u << (WH & 31)) - 1u) : 0xffffffffu;
@@ -574,11 +574,18 @@ __device__ inline void render_obs(const D &d, const uint32_t *g, uint32_t *ob, c
     // expand: float4 j of the observation = bits 4j..4j+3 of the bitstring, i.e. nibble (j & 7) of word
     // j >> 3, looked up in the wave's 16-entry float4 table (one conflict-free ds_read_b128, no VALU
     // selects); lanes 8q..8q+7 share a word and the nibble position of a lane never changes.
-    float4 *dst = reinterpret_cast<float4 *>(obs_env);
-    const uint32_t sh = (uint32_t)(lane & 7) * 4u;
+    if (as_bits) {
+        // INV_STEP_OBS_BITS: the bitstring itself is the output (bit c*W*H + y*W + x <=> obs[c][y][x] == 1.0f);
+        // obs_env then points at uint32_t[OW] (pad bits of the last word are zero)
+        uint32_t *bdst = reinterpret_cast<uint32_t *>(obs_env);
+        for (int w = lane; w < d.OW; w += kWave) bdst[w] = ob[w];
+    } else {
+        float4 *dst = reinterpret_cast<float4 *>(obs_env);
+        const uint32_t sh = (uint32_t)(lane & 7) * 4u;
 #pragma unroll 4
-    // (default-policy stores: non-temporal stores measured 30.7 us vs 20.0 us for this stream)
-    for (int j = lane; j < d.F4; j += kWave) dst[j] = tab[(ob[j >> 3] >> sh) & 15u];
+        // (default-policy stores: non-temporal stores measured 30.7 us vs 20.0 us for this stream)
+        for (int j = lane; j < d.F4; j += kWave) dst[j] = tab[(ob[j >> 3] >> sh) & 15u];
+    }
     if (extra_env && lane < 4) {                                            // :238-243: f32(ammo / 6) computed in f64
         const Player &q = (lane & 1) ? en : me;
         float val;

@@ -35,6 +35,7 @@ namespace pol {
 
 constexpr int H = 10, W = 15, P = H * W;                 // 150 pixels
 constexpr int PW = W + 2, PH = H + 2, NPOS = PW * PH;    // 12 x 17 haloed tile, 204 positions
+constexpr int OBS_WORDS = (12 * W * H + 31) / 32;          // 57 u32 words of one packed observation
 constexpr int CSTRIDE = 136;                             // bf16 per position: 128 channels + 8 pad = 272 B
 constexpr int THREADS = 256, WAVES = THREADS / 64;       // 4 waves per block, 2 blocks per CU (55 KB LDS each)
 constexpr float LN_EPS = 1e-5f;
@@ -212,11 +213,16 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     STAMP(9 + layer);                                                // epilogue + barrier
 }
 
-__global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params prm, const float *__restrict__ obs,
+// BITS: the observation arrives as the packed bitstring inv_step writes under INV_STEP_OBS_BITS (57 words per sample).
+template <bool BITS>
+__global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params prm, const void *__restrict__ obs_in,
                                                           bf16 *__restrict__ feat, int N)
 {
     __shared__ __attribute__((aligned(16))) bf16 tile[NPOS * CSTRIDE];         // 55 488 B: layers run in place -> 2 blocks / CU
     __shared__ float red[2 * WAVES];
+    __shared__ uint32_t obw[BITS ? OBS_WORDS : 1];                             // BITS: the current sample's bitstring
+    const float *obs = reinterpret_cast<const float *>(obs_in);
+    const uint32_t *obits = reinterpret_cast<const uint32_t *>(obs_in);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));   // uniform -> tile ownership and weight pointers in SGPRs
 
@@ -227,6 +233,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
         for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
         reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
     }
+    if (BITS && tid < OBS_WORDS && (int)blockIdx.x < N) obw[tid] = obits[(size_t)blockIdx.x * OBS_WORDS + tid];
     __syncthreads();
 
     unsigned long long stamp_prev = 0;
@@ -239,9 +246,26 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
         // around the MFMA loops.  Laundering the lane id makes them cheap per-sample recomputations instead.
         int lane_i = lane;
         asm volatile("" : "+v"(lane_i));
-        // observation f32 [12][150] -> tile, channels-last, 32 channels (12..31 zero: the k-step is 32 wide).
-        // Both float4 loads of a thread are issued before anything is converted (one HBM round trip, not 19).
-        {
+        // observation -> tile, channels-last, 32 channels (12..31 zero: the k-step is 32 wide).
+        uint32_t next_word = 0u;
+        if (BITS) {
+            // the NEXT sample's 57 words are requested now and parked in a register until the end of this sample
+            const int nn = n + (int)gridDim.x;
+            if (tid < OBS_WORDS && nn < N) next_word = obits[(size_t)nn * OBS_WORDS + tid];
+            // one 8-byte quad (4 channels) of a pixel per work item: quads 0..2 = channels 0..11 from the bitstring
+            // (bit c*150 + p; bf16 1.0 = 0x3F80), quads 3..7 = the zero pad
+            for (int z = tid; z < P * 8; z += THREADS) {
+                const int p = z >> 3, part = z & 7;
+                uint32_t lo = 0u, hi = 0u;
+                if (part < 3) {
+                    const int b0 = (4 * part) * P + p, b1 = b0 + P, b2 = b1 + P, b3 = b2 + P;
+                    lo = (((obw[b0 >> 5] >> (b0 & 31)) & 1u) * 0x3F80u) | (((obw[b1 >> 5] >> (b1 & 31)) & 1u) * 0x3F800000u);
+                    hi = (((obw[b2 >> 5] >> (b2 & 31)) & 1u) * 0x3F80u) | (((obw[b3 >> 5] >> (b3 & 31)) & 1u) * 0x3F800000u);
+                }
+                *reinterpret_cast<uint2 *>(&tile[pos_of(p) * CSTRIDE + part * 4]) = make_uint2(lo, hi);
+            }
+        } else {
+            // f32 [12][150]: both float4 loads of a thread are issued before anything is converted (one HBM round trip, not 19).
             const float4 *o4 = reinterpret_cast<const float4 *>(obs + (size_t)n * 12 * P);     // 450 float4 per sample
             const int q0 = tid, q1 = tid + THREADS;
             const float4 v0 = o4[q0];
@@ -284,6 +308,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
             const int p = q >> 4, part = q & 15;
             dst[q] = *reinterpret_cast<const bf16x8 *>(&tile[pos_of(p) * CSTRIDE + part * 8]);
         }
+        if (BITS && tid < OBS_WORDS) obw[tid] = next_word;        // every read of obw happened before the first barrier of this sample
         __syncthreads();
         STAMP(13);                                                   // feature write-out
     }
@@ -303,7 +328,7 @@ extern "C" int inv_policy_debug_stamps(unsigned long long *out16_host, int reset
 }
 #endif
 
-extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *obs, void *feat_bf16, int32_t N, void *stream)
+static int launch_trunk(const inv_policy_params *params, const void *obs, bool bits, void *feat_bf16, int32_t N, void *stream)
 {
     if (!params || !obs || !feat_bf16 || N < 0) return INV_ERR_BAD_ARG;
     if (N == 0) return INV_OK;
@@ -316,7 +341,21 @@ extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *ob
         else cus = 256;
     }
     const int grid = N < 2 * cus ? N : 2 * cus;     // two resident 256-thread workgroups per CU (55 KB of LDS each), persistent over samples
-    hipLaunchKernelGGL(pol::k_policy_trunk, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
-                       reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N);
+    if (bits)
+        hipLaunchKernelGGL(pol::k_policy_trunk<true>, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N);
+    else
+        hipLaunchKernelGGL(pol::k_policy_trunk<false>, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+}
+
+extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *obs, void *feat_bf16, int32_t N, void *stream)
+{
+    return launch_trunk(params, obs, false, feat_bf16, N, stream);
+}
+
+extern "C" int inv_policy_trunk_bits(const inv_policy_params *params, const uint32_t *bits, void *feat_bf16, int32_t N, void *stream)
+{
+    return launch_trunk(params, bits, true, feat_bf16, N, stream);
 }

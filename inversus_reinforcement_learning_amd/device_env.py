@@ -44,6 +44,7 @@ class DeviceEnvBatch:
             difficulty = "hard"                                             # env_wrappers.py:81-89: anything else is the hard branch
         self.num_envs, self.W, self.H, self.K = int(num_envs), int(width), int(height), int(max_bullets)
         self.GW = (self.W * self.H + 31) // 32
+        self.OW = (12 * self.W * self.H + 31) // 32          # u32 words of one packed observation
         self.opponent, self.difficulty = opponent, difficulty
         self.max_episode_steps = int(max_episode_steps)
         self.env_offset = int(env_offset)
@@ -70,6 +71,23 @@ class DeviceEnvBatch:
 
     def obs_shape(self, lead=()):
         return tuple(lead) + (self.num_envs, 12, self.H, self.W)
+
+    def _new_obs(self, lead, bits):
+        """f32 planes [.., N, 12, H, W], or the packed form [.., N, OW] int32 (INV_STEP_OBS_BITS)."""
+        if bits:
+            return self._new(tuple(lead) + (self.num_envs, self.OW), torch.int32)
+        return self._new(self.obs_shape(lead), torch.float32)
+
+    def _is_bits(self, r):
+        """Packed or f32 output buffers?  (both perspectives must agree: the flag is per launch)"""
+        kinds = {t.dtype for t in (r.obs, r.obs_p2) if t is not None}
+        if len(kinds) > 1 or not kinds <= {torch.float32, torch.int32}:
+            raise ValueError("obs / obs_p2 buffers must both be float32 planes or both int32 packed bitstrings")
+        bits = kinds == {torch.int32}
+        for t in (r.obs, r.obs_p2):
+            if t is not None and tuple(t.shape[-1:] if bits else t.shape[-3:]) != ((self.OW,) if bits else (12, self.H, self.W)):
+                raise ValueError(f"observation buffer has the wrong trailing shape: {tuple(t.shape)}")
+        return bits
 
     def _as_actions(self, a, lead=()):
         if a is None:
@@ -107,14 +125,14 @@ class DeviceEnvBatch:
             L.raise_for(self.lib.inv_check(self.h, _stream()), self.lib)
 
     # ------------------------------------------------------------------ step / render
-    def _alloc_out(self, lead, obs, obs_p2, reward64, out):
+    def _alloc_out(self, lead, obs, obs_p2, reward64, out, bits=False):
         if out is not None:
             return out
         n = self.num_envs
         r = StepResult(
-            obs=self._new(self.obs_shape(lead), torch.float32) if obs else None,
+            obs=self._new_obs(lead, bits) if obs else None,
             extra=self._new(tuple(lead) + (n, 4), torch.float32) if obs else None,
-            obs_p2=self._new(self.obs_shape(lead), torch.float32) if obs_p2 else None,
+            obs_p2=self._new_obs(lead, bits) if obs_p2 else None,
             extra_p2=self._new(tuple(lead) + (n, 4), torch.float32) if obs_p2 else None,
             reward=self._new(tuple(lead) + (n,), torch.float32),
             reward64=self._new(tuple(lead) + (n,), torch.float64) if reward64 else None,
@@ -130,12 +148,13 @@ class DeviceEnvBatch:
         return L.InvStepOut(*[_ptr(getattr(r, k)) for k in StepResult.__slots__])
 
     def step(self, a1, a2=None, auto_reset=False, flags=L.INV_STEP_DEFAULT, obs=True, obs_p2=False,
-             reward64=False, out=None, mask=None):
-        """One vector step.  a2=None uses the device dummy opponent (opponent="dummy" only)."""
+             reward64=False, out=None, mask=None, bits=False):
+        """One vector step.  a2=None uses the device dummy opponent (opponent="dummy" only).
+        bits=True (or int32 buffers in `out`): observations as packed bitstrings [N, OW] int32."""
         a1t, a2t = self._as_actions(a1), self._as_actions(a2)
-        r = self._alloc_out((), obs, obs_p2, reward64, out)
+        r = self._alloc_out((), obs, obs_p2, reward64, out, bits)
         co = self._c_out(r)
-        fl = int(flags) | (L.INV_STEP_AUTO_RESET if auto_reset else 0)
+        fl = int(flags) | (L.INV_STEP_AUTO_RESET if auto_reset else 0) | (L.INV_STEP_OBS_BITS if self._is_bits(r) else 0)
         with torch.cuda.device(self.device):
             if mask is None:
                 rc = self.lib.inv_step(self.h, _ptr(a1t), _ptr(a2t), fl, C.byref(co), _stream())
@@ -150,7 +169,7 @@ class DeviceEnvBatch:
         launch-rate-sensitive loops (the per-step Python marshalling of step() is ~20 us)."""
         co = self._c_out(out)
         a2t = self._as_actions(a2)
-        fl = int(flags) | (L.INV_STEP_AUTO_RESET if auto_reset else 0)
+        fl = int(flags) | (L.INV_STEP_AUTO_RESET if auto_reset else 0) | (L.INV_STEP_OBS_BITS if self._is_bits(out) else 0)
         fn, h, ref, a2p, st = self.lib.inv_step, self.h, C.byref(co), _ptr(a2t), _stream()
         lib = self.lib
 
@@ -161,22 +180,25 @@ class DeviceEnvBatch:
         step.keepalive = (co, out, a2t)
         return step
 
-    def rollout(self, a1, a2=None, obs=True, obs_p2=False, reward64=False, out=None):
+    def rollout(self, a1, a2=None, obs=True, obs_p2=False, reward64=False, out=None, bits=False):
         """T vector steps in one launch with pre-supplied actions a1[T, N] (always auto-resets)."""
         T = int(a1.shape[0])
         a1t, a2t = self._as_actions(a1, (T,)), self._as_actions(a2, (T,))
-        r = self._alloc_out((T,), obs, obs_p2, reward64, out)
+        r = self._alloc_out((T,), obs, obs_p2, reward64, out, bits)
         co = self._c_out(r)
+        fl = L.INV_STEP_OBS_BITS if self._is_bits(r) else 0
         with torch.cuda.device(self.device):
-            L.raise_for(self.lib.inv_rollout(self.h, T, _ptr(a1t), _ptr(a2t), C.byref(co), _stream()), self.lib)
+            L.raise_for(self.lib.inv_rollout(self.h, T, _ptr(a1t), _ptr(a2t), fl, C.byref(co), _stream()), self.lib)
         return r
 
-    def render(self, player=0, out=None):
-        """build_observation for every env: (grid[N,12,H,W], extra[N,4]) device tensors."""
+    def render(self, player=0, out=None, bits=False):
+        """build_observation for every env: (grid[N,12,H,W], extra[N,4]) device tensors; bits=True (or an
+        int32 out[0]): the grid as packed bitstrings [N, OW] int32."""
         if out is None:
-            out = (self._new(self.obs_shape(), torch.float32), self._new((self.num_envs, 4), torch.float32))
+            out = (self._new_obs((), bits), self._new((self.num_envs, 4), torch.float32))
+        fn = self.lib.inv_render_obs_bits if out[0].dtype == torch.int32 else self.lib.inv_render_obs
         with torch.cuda.device(self.device):
-            L.raise_for(self.lib.inv_render_obs(self.h, int(player), _ptr(out[0]), _ptr(out[1]), _stream()), self.lib)
+            L.raise_for(fn(self.h, int(player), _ptr(out[0]), _ptr(out[1]), _stream()), self.lib)
         return out
 
     def uniform_actions(self, seed, t, out=None):
@@ -225,6 +247,26 @@ class DeviceEnvBatch:
         with torch.cuda.device(self.device):
             L.raise_for(self.lib.inv_set_state(self.h, C.byref(view), _stream()), self.lib)
             torch.cuda.current_stream().synchronize()      # keep the staging tensors alive until consumed
+
+
+def unpack_obs(bits, height=10, width=15, out=None):
+    """Packed observations [..., OW] int32 (INV_STEP_OBS_BITS) -> f32 planes [..., 12, H, W]; exact."""
+    lib = L.load()
+    if bits.dtype != torch.int32 or not bits.is_cuda:
+        raise ValueError("unpack_obs expects a CUDA int32 tensor of packed observations")
+    floats = 12 * int(height) * int(width)
+    if bits.shape[-1] != (floats + 31) // 32:
+        raise ValueError(f"packed observations of a {width}x{height} board have {(floats + 31) // 32} words, got {bits.shape[-1]}")
+    b = bits.contiguous()
+    lead = tuple(b.shape[:-1])
+    n = int(np.prod(lead)) if lead else 1
+    if out is None:
+        out = torch.empty(lead + (12, int(height), int(width)), dtype=torch.float32, device=b.device)
+    elif out.dtype != torch.float32 or out.numel() != n * floats or not out.is_contiguous():
+        raise ValueError("unpack_obs: `out` must be a contiguous float32 tensor of matching size")
+    with torch.cuda.device(b.device):
+        L.raise_for(lib.inv_unpack_obs(_ptr(b), n, floats, _ptr(out), _stream()), lib)
+    return out
 
 
 def gae(rewards, values, dones, gamma=0.99, lam=0.95, last_value=None, layout="per_env"):

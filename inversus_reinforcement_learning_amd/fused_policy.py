@@ -29,7 +29,7 @@ def _pack_conv(w, cin_pad):
 
 
 class FusedPolicy:
-    """Callable like the module in eval mode: (grid f32 [B,12,10,15], extra f32 [B,4]) -> (logits, value)."""
+    """Callable like the module in eval mode: (grid f32 [B,12,10,15] or packed int32 [B,57], extra f32 [B,4]) -> (logits, value)."""
 
     def __init__(self, policy):
         self.policy = policy
@@ -66,12 +66,18 @@ class FusedPolicy:
 
     @torch.no_grad()
     def features(self, grid):
-        """Trunk only: bf16 [B, 19200] in channels-last order."""
-        grid = grid.contiguous().float()
+        """Trunk only: bf16 [B, 19200] in channels-last order.  `grid`: f32 planes [B,12,10,15] or the packed
+        observations [B, 57] int32 that the env writes under INV_STEP_OBS_BITS (32x fewer bytes to read)."""
+        if grid.dtype == torch.int32:
+            if grid.dim() != 2 or grid.shape[1] != 57:
+                raise ValueError(f"packed observations must be [B, 57] int32, got {tuple(grid.shape)}")
+            grid, fn = grid.contiguous(), self.lib.inv_policy_trunk_bits
+        else:
+            grid, fn = grid.contiguous().float(), self.lib.inv_policy_trunk
         feat = torch.empty((grid.shape[0], 19200), dtype=torch.bfloat16, device=grid.device)
         with torch.cuda.device(grid.device):
-            rc = self.lib.inv_policy_trunk(C.byref(self.params), C.c_void_p(grid.data_ptr()), C.c_void_p(feat.data_ptr()),
-                                           grid.shape[0], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            rc = fn(C.byref(self.params), C.c_void_p(grid.data_ptr()), C.c_void_p(feat.data_ptr()),
+                    grid.shape[0], C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.raise_for(rc, self.lib)
         return feat
 

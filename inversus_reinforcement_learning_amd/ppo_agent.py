@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from . import parallel
-from .device_env import gae as device_gae
+from .device_env import gae as device_gae, unpack_obs
 
 
 class PPOAgent:
@@ -56,6 +56,18 @@ class PPOAgent:
     def _t(self, x, dtype):
         return torch.as_tensor(x, dtype=dtype, device=self.device)
 
+    @staticmethod
+    def _packed(x):
+        """Packed observations (int32 bitstrings written under INV_STEP_OBS_BITS) instead of f32 planes?"""
+        return torch.is_tensor(x) and x.dtype == torch.int32
+
+    def _planes(self, grid):
+        """f32 planes for the autograd module, expanding packed observations (exact: entries are 0.0 / 1.0)."""
+        if self._packed(grid):
+            _, h, w = self.policy.norm1.normalized_shape
+            return unpack_obs(grid, h, w)
+        return self._t(grid, torch.float32)
+
     def store_step(self, grid_tensor, extra_vector, action, log_prob, value, reward, done):
         """One transition (the reference's per-env call) -- kept for API compatibility."""
         self.store_batch(self._t(grid_tensor, torch.float32)[None], self._t(extra_vector, torch.float32)[None],
@@ -63,8 +75,10 @@ class PPOAgent:
                          self._t([value], torch.float32), self._t([reward], torch.float32), self._t([done], torch.bool))
 
     def store_batch(self, grid, extra, actions, log_probs, values, rewards, dones):
-        """One vector step: [N,...] tensors, appended in env order (== the reference's fill order)."""
-        self.obs_grid_buffer.append(self._t(grid, torch.float32))
+        """One vector step: [N,...] tensors, appended in env order (== the reference's fill order).
+        `grid` may be the packed int32 form; it is stored as is (228 B instead of 7 200 B per observation)
+        and expanded per minibatch in update()."""
+        self.obs_grid_buffer.append(grid if self._packed(grid) else self._t(grid, torch.float32))
         self.obs_extra_buffer.append(self._t(extra, torch.float32))
         self.action_buffer.append(self._t(actions, torch.int64))
         self.log_prob_buffer.append(self._t(log_probs, torch.float32))
@@ -79,8 +93,11 @@ class PPOAgent:
         tensors out (actions int64, log_probs f32, values f32)."""
         as_numpy = not isinstance(grid_tensors, torch.Tensor)
         self.policy.eval()
-        fwd = self.fused if self.fused is not None else self.policy
-        logits, values = fwd(self._t(grid_tensors, torch.float32), self._t(extra_vectors, torch.float32))
+        if self.fused is not None:                                # reads f32 planes or packed observations directly
+            logits, values = self.fused(grid_tensors if self._packed(grid_tensors) else self._t(grid_tensors, torch.float32),
+                                        self._t(extra_vectors, torch.float32))
+        else:
+            logits, values = self.policy(self._planes(grid_tensors), self._t(extra_vectors, torch.float32))
         dist = torch.distributions.Categorical(logits=logits)
         actions = dist.sample()
         log_probs = dist.log_prob(actions)
@@ -142,7 +159,7 @@ class PPOAgent:
                 idx = indices[start:start + self.batch_size]
                 with torch.autocast(self.device.type, dtype=self.update_autocast or torch.bfloat16,
                                     enabled=self.update_autocast is not None):
-                    logits, values = self.policy(obs_grid[idx], obs_extra[idx])
+                    logits, values = self.policy(self._planes(obs_grid[idx]), obs_extra[idx])
                 logits, values = logits.float(), values.float()
                 dist = torch.distributions.Categorical(logits=logits)
                 new_log_probs = dist.log_prob(actions[idx])

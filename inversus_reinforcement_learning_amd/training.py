@@ -19,7 +19,7 @@ import torch
 
 from . import _lib as L
 from . import parallel
-from .device_env import DeviceEnvBatch
+from .device_env import DeviceEnvBatch, unpack_obs
 from .policies import InversusCNNPolicy
 from .ppo_agent import PPOAgent
 
@@ -49,21 +49,28 @@ class RolloutCollector:
                a1 / a2 come from one batched forward of `policy` / `opponent` each (the reference
                does N batch-of-1 forwards, training.py:249-258)."""
 
-    def __init__(self, batch, agent, opponent=None):
+    def __init__(self, batch, agent, opponent=None, packed_obs=None):
         self.batch, self.agent, self.opponent = batch, agent, opponent
         self.selfplay = batch.opponent == "selfplay"
         if self.selfplay and opponent is None:
             raise ValueError("opponent_policy required for selfplay mode")
-        self.out = batch._alloc_out((), True, self.selfplay, False, None)
-        self.obs = batch.render(0)
-        self.obs_p2 = batch.render(1) if self.selfplay else None
+        # packed_obs: the env writes 57-word bitstrings instead of f32 planes (INV_STEP_OBS_BITS); the fused trunk
+        # reads them directly and the rollout buffer shrinks 32x.  Default: on whenever every actor is fused.
+        if packed_obs is None:
+            packed_obs = agent.fused is not None and (opponent is None or not hasattr(opponent, "parameters"))
+        self.packed = bool(packed_obs)
+        self.obs = batch.render(0, bits=self.packed)
+        self.obs_p2 = batch.render(1, bits=self.packed) if self.selfplay else None
         self.episodes = {"return": [], "length": [], "win": []}
 
     @torch.no_grad()
     def _opponent_actions(self):
         if hasattr(self.opponent, "eval"):
             self.opponent.eval()
-        logits, _ = self.opponent(self.obs_p2[0], self.obs_p2[1])
+        grid = self.obs_p2[0]
+        if self.packed and hasattr(self.opponent, "parameters"):      # an nn.Module opponent wants f32 planes
+            grid = unpack_obs(grid, self.batch.H, self.batch.W)
+        logits, _ = self.opponent(grid, self.obs_p2[1])
         return torch.distributions.Categorical(logits=logits).sample().to(torch.uint8)
 
     def collect(self, steps):
@@ -73,7 +80,7 @@ class RolloutCollector:
             actions, log_probs, values = agent.act(grid, extra)
             a2 = self._opponent_actions() if self.selfplay else None
             # fresh obs buffers per step: the rollout buffer keeps references to them (ppo_agent.py:119)
-            out = b._alloc_out((), True, self.selfplay, False, None)
+            out = b._alloc_out((), True, self.selfplay, False, None, self.packed)
             r = b.step(actions.to(torch.uint8), a2, auto_reset=True, out=out)
             agent.store_batch(grid, extra, actions, log_probs, values, r.reward, r.done)
             self.obs = (r.obs, r.extra)

@@ -32,7 +32,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in include/inversus_hip.h but not exported"
     lib = _lib.load()
     assert set(_lib.SIGNATURES) == set(declared_symbols())
-    assert lib.inv_abi_version() == 1
+    assert lib.inv_abi_version() == 2
 
 
 def test_code_object_is_gfx950():

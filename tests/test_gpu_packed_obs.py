@@ -1,0 +1,206 @@
+"""GPU tests of the packed observation path (INV_STEP_OBS_BITS, inv_render_obs_bits, inv_unpack_obs,
+inv_policy_trunk_bits): the 12*H*W observation of build_observation (env_wrappers.py:173-245) as a
+bitstring, bit c*H*W + y*W + x.  Bar: bit-exact against the CPU oracle's observation and against the
+f32 path of the same library; the trunk's features from bits must EQUAL its features from f32 planes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make(n, W=15, H=10, **kw):
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    return DeviceEnvBatch(n, W, H, **kw)
+
+
+def words_of(planes):
+    """[N,12,H,W] 0/1 floats -> [N, OW] uint32 words, bit i of the bitstring = flat element i."""
+    a = np.asarray(planes)
+    assert np.all((a == 0.0) | (a == 1.0))
+    flat = a.reshape(a.shape[0], -1) != 0
+    pad = (-flat.shape[1]) % 32
+    flat = np.pad(flat, ((0, 0), (0, pad)))
+    return np.packbits(flat, axis=1, bitorder="little").view("<u4")
+
+
+def as_u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("W,H,n,T", [(15, 10, 1024, 120), (32, 32, 256, 60), (7, 5, 300, 80), (64, 64, 32, 40), (3, 3, 64, 30)])
+def test_packed_step_output_vs_oracle_and_f32_path(W, H, n, T):
+    """Self-play stepping with auto-reset: packed P1 / P2 observations == the oracle's observation, bit for bit,
+    == the f32 planes of a twin batch; inv_unpack_obs inverts the packing; extras are unaffected."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import unpack_obs
+    from oracle import oracle as orc
+    seeds = 31 + np.arange(n, dtype=np.int64)
+    rng = np.random.RandomState(5)
+    bb, bf = make(n, W, H, opponent="selfplay", max_episode_steps=40), make(n, W, H, opponent="selfplay", max_episode_steps=40)
+    ob = orc.OracleBatch(n, W, H, max_episode_steps=40)
+    for b in (bb, bf):
+        b.seed(seeds); b.reset()
+    ob.seed_reset(seeds)
+    assert bb.OW == (12 * W * H + 31) // 32
+    for t in range(T):
+        a = [np.where(rng.random_sample(n) < 0.5, rng.randint(5, 13, n), rng.randint(0, 13, n)).astype(np.uint8) for _ in range(2)]
+        rb = bb.step(a[0], a[1], auto_reset=True, obs_p2=True, bits=True)
+        rf = bf.step(a[0], a[1], auto_reset=True, obs_p2=True)
+        assert rb.obs.dtype == torch.int32 and tuple(rb.obs.shape) == (n, bb.OW)
+        o_obs, o_extra, *_ = ob.step(a[0], a[1], nthreads=8)
+        assert np.array_equal(as_u32(rb.obs), words_of(o_obs)), t
+        assert np.array_equal(as_u32(rb.obs), words_of(rf.obs.cpu().numpy())), t
+        assert np.array_equal(as_u32(rb.obs_p2), words_of(rf.obs_p2.cpu().numpy())), t
+        assert torch.equal(rb.extra, rf.extra) and torch.equal(rb.extra_p2, rf.extra_p2)
+        assert torch.equal(rb.reward, rf.reward) and torch.equal(rb.done, rf.done)
+        if t % 10 == 0:
+            assert torch.equal(unpack_obs(rb.obs, H, W), rf.obs) and torch.equal(unpack_obs(rb.obs_p2, H, W), rf.obs_p2)
+    bb.check(); bf.check()
+    sb, sf = bb.get_state(), bf.get_state()
+    for k in sb:
+        assert np.array_equal(sb[k], sf[k]), k
+
+
+def test_render_bits_rollout_bits_and_masked_step():
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import unpack_obs
+    n, T = 777, 24                                  # ragged: not a multiple of the 4 envs per block
+    seeds = 900 + np.arange(n, dtype=np.int64)
+    rng = np.random.RandomState(2)
+    a1 = rng.randint(0, 13, (T, n)).astype(np.uint8)
+    b1, b2 = make(n, opponent="dummy", difficulty="hard", opp_seed=9), make(n, opponent="dummy", difficulty="hard", opp_seed=9)
+    for b in (b1, b2):
+        b.seed(seeds); b.reset()
+    for p in (0, 1):
+        gb, xb = b1.render(p, bits=True)
+        gf, xf = b1.render(p)
+        assert np.array_equal(as_u32(gb), words_of(gf.cpu().numpy())) and torch.equal(xb, xf)
+        assert torch.equal(unpack_obs(gb), gf)
+    rb = b1.rollout(a1, None, obs_p2=True, bits=True)
+    rf = b2.rollout(a1, None, obs_p2=True)
+    assert tuple(rb.obs.shape) == (T, n, 57)
+    assert torch.equal(unpack_obs(rb.obs), rf.obs) and torch.equal(unpack_obs(rb.obs_p2), rf.obs_p2)
+    assert torch.equal(rb.reward, rf.reward) and torch.equal(rb.extra, rf.extra)
+    # masked step: slots of envs that do not step keep their previous contents
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    out = b1._alloc_out((), True, False, False, None, True)
+    out.obs.fill_(-1)
+    b1.step(a1[0], None, out=out, mask=mask)
+    ref = b2.step(a1[0], None, mask=mask, out=None)
+    got = as_u32(out.obs)
+    assert np.all(got[mask == 0] == 0xFFFFFFFF)
+    assert np.array_equal(got[mask == 1], words_of(ref.obs.cpu().numpy())[mask == 1])
+    b1.check(); b2.check()
+
+
+def test_unpack_obs_argument_checks_and_exhaustive_nibbles():
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import unpack_obs
+    rng = np.random.RandomState(0)
+    w = rng.randint(0, 2 ** 32, (33, 57), dtype=np.uint64).astype(np.uint32)
+    w[:, 56] &= (1 << (1800 - 56 * 32)) - 1         # pad bits are zero in anything the env writes
+    t = torch.from_numpy(w.view(np.int32)).cuda()
+    planes = unpack_obs(t)
+    assert tuple(planes.shape) == (33, 12, 10, 15)
+    assert np.array_equal(words_of(planes.cpu().numpy()), w)
+    lead = unpack_obs(t.reshape(3, 11, 57))
+    assert tuple(lead.shape) == (3, 11, 12, 10, 15) and torch.equal(lead.reshape(33, 12, 10, 15), planes)
+    with pytest.raises(ValueError):
+        unpack_obs(t[:, :56])
+    with pytest.raises(ValueError):
+        unpack_obs(t.float())
+    b = make(8)
+    b.seed(np.arange(8, dtype=np.int64)); b.reset()
+    mixed = b._alloc_out((), True, True, False, None, True)
+    mixed.obs_p2 = torch.zeros(8, 12, 10, 15, device="cuda")          # one packed, one f32: the flag is per launch
+    with pytest.raises(ValueError):
+        b.step(np.zeros(8, np.uint8), None, out=mixed)
+    wrong = b._alloc_out((), True, False, False, None, True)
+    wrong.obs = torch.zeros(8, 56, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        b.step(np.zeros(8, np.uint8), None, out=wrong)
+
+
+@pytest.mark.parametrize("n", [1, 5, 700, 2051])
+def test_trunk_from_bits_equals_trunk_from_planes(n):
+    """Same bf16 operands either way (every observation value is 0 or 1), so the features must be EQUAL --
+    including the persistent blocks' next-sample prefetch at N > grid size."""
+    import torch
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    torch.manual_seed(3)
+    f = FusedPolicy(InversusCNNPolicy(12, 10, 15, 4).cuda().eval())
+    b = make(n, opponent="selfplay")
+    b.seed(70 + np.arange(n, dtype=np.int64)); b.reset()
+    rng = np.random.RandomState(1)
+    for _ in range(6):
+        b.step(rng.randint(0, 13, n).astype(np.uint8), rng.randint(0, 13, n).astype(np.uint8), auto_reset=True, obs=False)
+    for p in (0, 1):
+        gb, x = b.render(p, bits=True)
+        gf, _ = b.render(p)
+        assert torch.equal(f.features(gb), f.features(gf))
+        lb, vb = f(gb, x)
+        lf, vf = f(gf, x)
+        assert torch.equal(lb, lf) and torch.equal(vb, vf)
+    with pytest.raises(ValueError):
+        f.features(torch.zeros(4, 56, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("mode", ["dummy", "selfplay"])
+def test_collector_with_packed_observations_equals_f32_collector(mode):
+    """Fused actor(s): the packed collector (the default then) stores int32 bitstrings, samples the same actions,
+    sees the same rewards and makes the same PPO update as the f32-plane collector."""
+    import torch
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    from inversus_reinforcement_learning_amd.device_env import unpack_obs
+    n, T = 192, 12
+    res = []
+    for packed in (None, False):
+        torch.manual_seed(11)
+        b = make(n, opponent=mode, difficulty="hard", opp_seed=4, max_episode_steps=30)
+        b.seed(np.arange(n, dtype=np.int64)); b.reset()
+        agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), fused_act=True, batch_size=768, epochs=1)
+        opp = None
+        if mode == "selfplay":
+            opp = FusedPolicy(InversusCNNPolicy(12, 10, 15, 4).cuda().eval())
+        col = RolloutCollector(b, agent, opp, packed_obs=packed)
+        assert col.packed == (packed is None)
+        col.collect(T)
+        grids = torch.stack(agent.obs_grid_buffer)
+        assert grids.dtype == (torch.int32 if col.packed else torch.float32)
+        pack = {"grid": unpack_obs(grids) if col.packed else grids, "a": torch.stack(agent.action_buffer),
+                "r": torch.stack(agent.reward_buffer), "lp": torch.stack(agent.log_prob_buffer)}
+        stats = agent.update()
+        pack["params"] = torch.cat([p.detach().reshape(-1) for p in agent.policy.parameters()])
+        res.append((pack, stats))
+    for k in res[0][0]:
+        if k == "params":           # same minibatches, but the conv weight gradients are reduced with atomics (run-to-run noise)
+            assert torch.allclose(res[0][0][k], res[1][0][k], atol=2e-4, rtol=0), k
+        else:
+            assert torch.equal(res[0][0][k], res[1][0][k]), k
+    for k in res[0][1]:
+        assert res[0][1][k] == pytest.approx(res[1][1][k], rel=1e-3, abs=1e-4), k
+
+
+def test_packed_collector_with_module_opponent_and_unfused_agent():
+    """packed_obs=True also works when an actor is the plain nn.Module (observations are expanded for it)."""
+    import torch
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    n = 64
+    outs = []
+    for packed in (True, False):
+        torch.manual_seed(5)
+        b = make(n, opponent="selfplay")
+        b.seed(np.arange(n, dtype=np.int64)); b.reset()
+        agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), batch_size=256, epochs=1)
+        opp = InversusCNNPolicy(12, 10, 15, 4).cuda().eval()
+        col = RolloutCollector(b, agent, opp, packed_obs=packed)
+        col.collect(6)
+        outs.append((torch.stack(agent.action_buffer), torch.stack(agent.reward_buffer)))
+        assert all(np.isfinite(list(agent.update().values())))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
