@@ -111,11 +111,11 @@ def side_measurements(torch, np, n):
         except Exception as exc:                          # pragma: no cover
             out[name] = f"failed: {type(exc).__name__}: {exc}"
 
-    def step_cfg(W_, H_, opponent, difficulty, obs_p2, selfplay_bytes):
+    def step_cfg(W_, H_, opponent, difficulty, obs_p2, selfplay_bytes, bits=False):
         def run():
             b = DeviceEnvBatch(n, W_, H_, K, opponent=opponent, difficulty=difficulty, opp_seed=1)
             b.seed(np.arange(n, dtype=np.int64)); b.reset()
-            o = b._alloc_out((), True, obs_p2, False, None)
+            o = b._alloc_out((), True, obs_p2, False, None, bits)
             acts = torch.stack([b.uniform_actions(5, t) for t in range(64)])
             a2 = torch.stack([b.uniform_actions(6, t) for t in range(64)]) if opponent == "selfplay" else None
             k = [0]
@@ -128,12 +128,15 @@ def side_measurements(torch, np, n):
                 steppers[j](acts[j].data_ptr())
             us = timed(f, 128, warm=64)
             by = algorithmic_bytes_per_env_step(W_, H_, K, selfplay=selfplay_bytes) * n
+            if bits:                                      # packed observations: OW words instead of 12*W*H floats per perspective
+                by -= (2 if obs_p2 else 1) * (12 * W_ * H_ * 4 - 4 * ((12 * W_ * H_ + 31) // 32)) * n
             return {"us_per_vector_step": round(us, 2), "env_steps_per_s": round(n / us * 1e6), "GBps": round(by / us / 1e3, 1)}
         return run
 
     guard("step vs_dummy_hard 15x10", step_cfg(15, 10, "dummy", "hard", False, False))
     guard("step selfplay 15x10 (P1+P2 obs)", step_cfg(15, 10, "selfplay", "easy", True, True))
     guard("step vs_dummy_hard 32x32 K=16 (C5)", step_cfg(32, 32, "dummy", "hard", False, False))
+    guard("step selfplay 15x10, PACKED P1+P2 obs (INV_STEP_OBS_BITS)", step_cfg(15, 10, "selfplay", "easy", True, True, bits=True))
 
     def gae_cfg():
         T = 128
@@ -156,17 +159,21 @@ def side_measurements(torch, np, n):
         res = {"fused_trunk_ms": round(timed(lambda: fused.features(g), 5) / 1e3, 3),
                "fused_forward_ms": round(timed(lambda: fused(g, x), 5) / 1e3, 3)}
         res["fused_trunk_TFLOPs"] = round(72.9e6 * n / (res["fused_trunk_ms"] * 1e-3) / 1e12, 1)
+        gbits = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, 57), dtype=torch.int32, device="cuda") & \
+            torch.randint(-2 ** 31, 2 ** 31 - 1, (n, 57), dtype=torch.int32, device="cuda")        # ~25 % ones
+        res["fused_trunk_packed_obs_ms"] = round(timed(lambda: fused.features(gbits), 5) / 1e3, 3)
         with torch.no_grad():
             res["torch_f32_forward_ms"] = round(timed(lambda: pol(g, x), 3, warm=1) / 1e3, 3)
         b = DeviceEnvBatch(n, opponent="selfplay")
         b.seed(np.arange(n, dtype=np.int64)); b.reset()
         agent = PPOAgent(pol, fused_act=True)
         opp = FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval())
-        col = RolloutCollector(b, agent, opp)
-        col.collect(2); agent.reset_buffers(); torch.cuda.synchronize()
-        t0 = time.perf_counter(); col.collect(8); torch.cuda.synchronize()
-        res["selfplay_collector_env_steps_per_s"] = round(8 * n / (time.perf_counter() - t0))
-        agent.reset_buffers()
+        for packed, key in ((True, "selfplay_collector_env_steps_per_s"), (False, "selfplay_collector_f32_obs_env_steps_per_s")):
+            col = RolloutCollector(b, agent, opp, packed_obs=packed)
+            col.collect(2); agent.reset_buffers(); torch.cuda.synchronize()
+            t0 = time.perf_counter(); col.collect(8); torch.cuda.synchronize()
+            res[key] = round(8 * n / (time.perf_counter() - t0))
+            agent.reset_buffers()
         return res
     guard("policy in the loop (selfplay, fused bf16 trunk, 2 forwards/step)", policy_cfg)
     return out

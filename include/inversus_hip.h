@@ -189,10 +189,11 @@ int  inv_rollout(inv_handle *h, int32_t T, const uint8_t *a1, const uint8_t *a2,
  *   w    bf16 [Cout/16][9*Cin_pad/32][64][8]  A fragments of v_mfma_f32_16x16x32_bf16: lane = 16*g + r holds
  *                                             W[cout = 16*mt + r][k = 32*ks + 8*g + j], k = (3*ky+kx)*Cin_pad + c
  *   bias f32  [Cout]
- *   lnw, lnb f32 [150][Cout]                  LayerNorm affine, transposed to [pixel][channel]
+ *   ln   fp16 [150][Cout/4][8]                LayerNorm affine per (pixel, 4 consecutive channels): {weight x4, bias x4}
+ *                                             (fp16: 11 significant bits, 8x finer than the bf16 activations it scales)
  * obs: f32 [N][12][10][15] (what inv_step writes); feat: bf16 [N][150][128] channels-last, i.e.
  * feature index pixel*128 + channel (the caller permutes the first Linear's columns accordingly). */
-typedef struct { const void *w; const float *bias; const float *lnw; const float *lnb; } inv_policy_layer;
+typedef struct { const void *w; const float *bias; const void *ln; } inv_policy_layer;
 typedef struct { inv_policy_layer layer[4]; } inv_policy_params;
 int  inv_policy_trunk(const inv_policy_params *params, const float *obs, void *feat_bf16, int32_t N, void *stream);
 /* Same trunk reading packed observations, bits: uint32_t[N][57] (INV_STEP_OBS_BITS layout of the 15 x 10 board):

@@ -41,7 +41,7 @@ class InvStateView(C.Structure):
 
 
 class InvPolicyLayer(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("lnw", C.c_void_p), ("lnb", C.c_void_p)]
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("ln", C.c_void_p)]
 
 
 class InvPolicyParams(C.Structure):

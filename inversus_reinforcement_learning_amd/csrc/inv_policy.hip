@@ -44,6 +44,7 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 __device__ __forceinline__ int pos_of(int p) { return (p / W + 1) * PW + (p % W) + 1; }
 
@@ -111,7 +112,10 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
 
     const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
-    constexpr int AD = 3;                                            // weight fragments are requested AD k-steps ahead (L2 latency)
+#ifndef POL_AD
+#define POL_AD 3
+#endif
+    constexpr int AD = POL_AD;                                            // weight fragments are requested AD k-steps ahead (L2 latency)
     bf16x8 a[AD + 1][MW], b[NW];
 #pragma unroll
     for (int d = 0; d < AD; ++d)
@@ -163,6 +167,26 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             }
         }
     }
+    // LayerNorm parameters travel in groups of G tiles (one L2 round trip per group, 2 x G float4 registers per
+    // lane).  POL_LNPIPE: group g+1 is requested before group g is consumed, and group 0 before the statistics
+    // reduction, so a wave sees one exposed round trip per layer instead of one per group.
+    constexpr int G = NW < 5 ? NW : 5, GPM = NW / G, NG = MW * GPM;
+    static_assert(NW % G == 0, "tiles per wave must be a multiple of the parameter group");
+#ifdef POL_LNPIPE
+    f16x8 ln[2][G];
+#else
+    f16x8 ln[1][G];
+#endif
+    // lp.ln: fp16 [pixel][COUT/4][8] = {weight x4, bias x4} of 4 consecutive channels: ONE 16-byte load per tile
+    auto load_group = [&](int g, int buf) {
+        const int mi = g / GPM, i0 = (g - mi * GPM) * G, ch0 = (m0 + mi) * 16 + 4 * kg;
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            ln[buf][j] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(lp.ln) + ((size_t)min(pix[i0 + j], P - 1) * COUT + ch0) * 2);
+    };
+#if defined(POL_LNPIPE) || defined(POL_LNPRE)
+    load_group(0, 0);
+#endif
     s = wave_sum(s);
     ss = wave_sum(ss);
     const int wave = threadIdx.x >> 6;
@@ -179,35 +203,34 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     const float shift = -mean * rstd;
 
 #pragma unroll
-    for (int mi = 0; mi < MW; ++mi) {
-        const int ch0 = (m0 + mi) * 16 + 4 * kg;
-        // LayerNorm parameter loads are issued five tiles at a time (one L2 round trip per group, 40 registers)
-        constexpr int G = NW < 5 ? NW : 5;
+    for (int g = 0; g < NG; ++g) {
+        const int mi = g / GPM, i0 = (g - mi * GPM) * G, ch0 = (m0 + mi) * 16 + 4 * kg;
+#ifdef POL_LNPIPE
+        const int buf = g & 1;
+        if (g + 1 < NG) load_group(g + 1, buf ^ 1);
+#elif defined(POL_LNPRE)
+        const int buf = 0;
+        if (g > 0) load_group(g, 0);
+#else
+        const int buf = 0;
+        load_group(g, 0);
+#endif
 #pragma unroll
-        for (int i0 = 0; i0 < NW; i0 += G) {
-            float4 lw[G], lb[G];
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const size_t po = (size_t)min(pix[i0 + j], P - 1) * COUT + ch0;
-                lw[j] = *reinterpret_cast<const float4 *>(lp.lnw + po);
-                lb[j] = *reinterpret_cast<const float4 *>(lp.lnb + po);
+        for (int j = 0; j < G; ++j) {
+            const int i = i0 + j;
+            if (i < ncount && pix[i] < P) {
+                bf16x4 o;
+                const f16x8 q = ln[buf][j];
+                o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), (float)q[0], (float)q[4]), 0.0f);
+                o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), (float)q[1], (float)q[5]), 0.0f);
+                o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), (float)q[2], (float)q[6]), 0.0f);
+                o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), (float)q[3], (float)q[7]), 0.0f);
+                // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
+                // above, and the residual read of this lane's own elements precedes this write
+                *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
             }
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const int i = i0 + j;
-                if (i < ncount && pix[i] < P) {
-                    bf16x4 o;
-                    o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), lw[j].x, lb[j].x), 0.0f);
-                    o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), lw[j].y, lb[j].y), 0.0f);
-                    o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), lw[j].z, lb[j].z), 0.0f);
-                    o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), lw[j].w, lb[j].w), 0.0f);
-                    // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
-                    // above, and the residual read of this lane's own elements precedes this write
-                    *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);                     // one group's parameter set live at a time
         }
+        __builtin_amdgcn_sched_barrier(0);                         // at most two groups' parameter sets live at a time
     }
     __syncthreads();
     STAMP(9 + layer);                                                // epilogue + barrier
@@ -294,14 +317,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
         }
         __syncthreads();
         STAMP(0);                                                    // observation load + conversion
-        // tile ownership (4 waves).  A weight fragment comes from L2 and is reused by NW MFMAs, an activation
-        // fragment comes from LDS and is reused by MW: conv3/4 give every wave 2 row blocks x ALL 10 pixel tiles, so
-        // each weight fragment is fetched exactly once per sample (the L2 -> CU weight stream, ~0.5 MB per sample,
-        // is what bounds this kernel once the matrix pipe is fed: at 8 waves x 5 tiles it was fetched twice).
+        // tile ownership (4 waves).  A weight fragment comes from L2 through the vector-memory path and is reused by
+        // NW MFMAs, an activation fragment comes from LDS and is reused by MW; MW x NW = 20 accumulator tiles is what
+        // the register file allows.  At 2 x 10 the LDS reads alone need the CU's full 128 B/clk while the MFMAs
+        // issue; conv3/4 use 4 row blocks x 5 pixel tiles (half the LDS traffic, each weight fragment fetched by two
+        // waves), which also leaves the register allocator enough room to keep the epilogue out of scratch.
         conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
+#if defined(POL_C2_MW2)
+        conv_ln_relu<32, 64, 2, 5, false, false>(prm.layer[1], tile, red, lane_i, (wave & 1) * 2, (wave >> 1) * 5, 5, stamp_prev, 1);
+#else
         conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
-        conv_ln_relu<64, 128, 2, 10, false, false>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2);
-        conv_ln_relu<128, 128, 2, 10, false, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3);
+#endif
+        conv_ln_relu<64, 128, 4, 5, false, false>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2);
+        conv_ln_relu<128, 128, 4, 5, false, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3);
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * P * 128);
         for (int q = tid; q < P * 16; q += THREADS) {
@@ -333,7 +361,7 @@ static int launch_trunk(const inv_policy_params *params, const void *obs, bool b
     if (!params || !obs || !feat_bf16 || N < 0) return INV_ERR_BAD_ARG;
     if (N == 0) return INV_OK;
     for (int l = 0; l < 4; ++l)
-        if (!params->layer[l].w || !params->layer[l].bias || !params->layer[l].lnw || !params->layer[l].lnb) return INV_ERR_BAD_ARG;
+        if (!params->layer[l].w || !params->layer[l].bias || !params->layer[l].ln) return INV_ERR_BAD_ARG;
     static int cus = 0;                              // CU count, queried once (not in a captured region)
     if (cus == 0) {
         int dev = 0, n = 0;

@@ -50,10 +50,12 @@ class FusedPolicy:
             cout = conv.out_channels
             w = _pack_conv(conv.weight.detach().float(), _CIN_PAD[i])
             b = conv.bias.detach().float().contiguous()
-            lnw = norm.weight.detach().float().reshape(cout, 150).t().contiguous()     # [pixel][channel]
-            lnb = norm.bias.detach().float().reshape(cout, 150).t().contiguous()
-            self._keep += [w, b, lnw, lnb]
-            params.layer[i] = L.InvPolicyLayer(w.data_ptr(), b.data_ptr(), lnw.data_ptr(), lnb.data_ptr())
+            # LayerNorm affine, [pixel][channel/4][weight x4 | bias x4] in fp16: one 16-byte load per accumulator tile
+            lnw = norm.weight.detach().float().reshape(cout, 150).t().reshape(150, cout // 4, 4)
+            lnb = norm.bias.detach().float().reshape(cout, 150).t().reshape(150, cout // 4, 4)
+            ln = torch.cat([lnw, lnb], dim=2).contiguous().to(torch.float16)
+            self._keep += [w, b, ln]
+            params.layer[i] = L.InvPolicyLayer(w.data_ptr(), b.data_ptr(), ln.data_ptr())
         self.params = params
         # heads: first Linear of actor and critic concatenated; columns permuted from the module's
         # flatten order (c*150 + pixel) to the kernel's channels-last order (pixel*128 + c)
