@@ -200,6 +200,29 @@ int  inv_policy_trunk(const inv_policy_params *params, const float *obs, void *f
  * 228 B instead of 7 200 B per sample, the next sample's words are fetched while the current one computes. */
 int  inv_policy_trunk_bits(const inv_policy_params *params, const uint32_t *bits, void *feat_bf16, int32_t N, void *stream);
 
+/* ---- the same trunk for the PPO update: forward that keeps what the backward needs, and the
+ * backward of LayerNorm/ReLU + the data gradient of the convolutions (ppo_agent.py:219-224 runs autograd over
+ * policies.py:91-99).  All tensors bf16 channels-last [N][150][C_l], C = 32, 64, 128, 128:
+ *   xhat[l]  normalised pre-activation (z - mean) * rstd of layer l        act[l]  ReLU output of layer l (l < 3; act 3 = feat)
+ *   rstd     f32 [N][4]
+ *   dy[l]    gradient wrt the LayerNorm output (after the ReLU mask): dln_w = sum_n dy * xhat, dln_b = sum_n dy
+ *   dz[l]    gradient wrt the convolution output: dbias = sum dz, dW = sum_n sum_p dz[p] (x) input[p + tap]
+ * The parameter gradients are reductions over the batch of these tensors (left to the caller's GEMM / reduction library).
+ * wt[l - 1] (l = 1..3): the weights of layer l transposed for the data gradient, packed like inv_policy_layer.w for a
+ * convolution with Cin <-> Cout swapped and the taps flipped: Wt[ci][8 - tap][co] = W[co][ci][tap]. */
+typedef struct { void *xhat[4]; void *act[3]; float *rstd; } inv_policy_saved;
+typedef struct { const void *wt[3]; const void *ln[4]; } inv_policy_bwd_params;
+typedef struct { void *dy[4]; void *dz[4]; } inv_policy_grads;
+int  inv_policy_trunk_train_fwd(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, void *feat_bf16,
+                                const inv_policy_saved *saved, int32_t N, void *stream);
+int  inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const inv_policy_saved *saved, const void *dfeat_bf16,
+                          const inv_policy_grads *grads, int32_t N, void *stream);
+/* Weight gradient of convolution `layer` (0..3): dw[co][tap][ci] += sum_n sum_p dz[n][p][co] * x[n][p + tap][ci], f32
+ * [Cout][9][CinP] (accumulated into: zero it first), tap = 3*ky + kx.  x: the layer's input, bf16 channels-last
+ * [N][150][CinP] with CinP = 16, 32, 64, 128 (layer 0: the 12 observation planes padded with 4 zero channels);
+ * dz: what inv_policy_trunk_bwd wrote.  MFMA over pixels through transposing LDS reads. */
+int  inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, int32_t N, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

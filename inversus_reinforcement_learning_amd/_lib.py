@@ -48,6 +48,18 @@ class InvPolicyParams(C.Structure):
     _fields_ = [("layer", InvPolicyLayer * 4)]
 
 
+class InvPolicySaved(C.Structure):
+    _fields_ = [("xhat", C.c_void_p * 4), ("act", C.c_void_p * 3), ("rstd", C.c_void_p)]
+
+
+class InvPolicyBwdParams(C.Structure):
+    _fields_ = [("wt", C.c_void_p * 3), ("ln", C.c_void_p * 4)]
+
+
+class InvPolicyGrads(C.Structure):
+    _fields_ = [("dy", C.c_void_p * 4), ("dz", C.c_void_p * 4)]
+
+
 _V = C.c_void_p
 SIGNATURES = {
     "inv_last_error": (C.c_char_p, []),
@@ -74,6 +86,9 @@ SIGNATURES = {
     "inv_rollout": (C.c_int, [_V, C.c_int32, _V, _V, C.c_uint32, P(InvStepOut), _V]),
     "inv_policy_trunk": (C.c_int, [P(InvPolicyParams), _V, _V, C.c_int32, _V]),
     "inv_policy_trunk_bits": (C.c_int, [P(InvPolicyParams), _V, _V, C.c_int32, _V]),
+    "inv_policy_trunk_train_fwd": (C.c_int, [P(InvPolicyParams), _V, C.c_int32, _V, P(InvPolicySaved), C.c_int32, _V]),
+    "inv_policy_trunk_bwd": (C.c_int, [P(InvPolicyBwdParams), P(InvPolicySaved), _V, P(InvPolicyGrads), C.c_int32, _V]),
+    "inv_policy_wgrad": (C.c_int, [C.c_int32, _V, _V, _V, C.c_int32, _V]),
 }
 
 _lib = None

@@ -24,6 +24,7 @@
 // bit-comparable with the f32 reference policy; tests bound the difference (tests/test_gpu_policy.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/inversus_hip.h"
 
@@ -88,9 +89,13 @@ __device__ __forceinline__ float wave_sum(float x)
 // The k loop is software-pipelined by hand: the weight fragments of tap t+1 and the activation fragments of
 // k-step s+1 are in flight while the MFMAs of k-step s issue (hipcc does not do this on its own: the first
 // version waited on every ds_read and on the L2 load of the next weights inside each k-step).
-template <int CIN, int COUT, int MW, int NW, bool RAGGED, bool RESIDUAL>
+// SAVE (training forward): additionally stores what the backward pass needs -- the normalised pre-activation
+// x^ = (z - mean) * rstd and the activation, both bf16 channels-last [150][COUT] of this sample, and rstd.
+struct LayerSave { bf16 *xhat; bf16 *act; float *rstd; };
+
+template <int CIN, int COUT, int MW, int NW, bool RAGGED, bool RESIDUAL, bool SAVE = false>
 __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *tile, float *red, int lane, int m0, int n0, int ncount,
-                                             unsigned long long &stamp_prev, int layer)
+                                             unsigned long long &stamp_prev, int layer, const LayerSave sv = LayerSave{ nullptr, nullptr, nullptr })
 {
     constexpr int KPT = CIN / 32, KS = 9 * KPT;
     const int c16 = lane & 15, kg = lane >> 4;
@@ -201,6 +206,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     const float var = fmaxf(SS / cnt - mean * mean, 0.0f);
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
     const float shift = -mean * rstd;
+    if (SAVE && threadIdx.x == 0) *sv.rstd = rstd;
 
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -221,10 +227,23 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             if (i < ncount && pix[i] < P) {
                 bf16x4 o;
                 const f16x8 q = ln[buf][j];
+                if (SAVE) {
+                    // the backward pass recomputes y = x^ * w + b from the ROUNDED x^ it reads back, so the forward
+                    // activation is computed from the same rounded value (consistent ReLU mask)
+                    bf16x4 xq;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xq[e] = (bf16)fmaf(acc[mi][i][e], rstd, shift);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)fmaxf(fmaf((float)xq[e], (float)q[e], (float)q[4 + e]), 0.0f);
+                    const size_t go = (size_t)pix[i] * COUT + ch0;
+                    *reinterpret_cast<bf16x4 *>(sv.xhat + go) = xq;
+                    if (sv.act) *reinterpret_cast<bf16x4 *>(sv.act + go) = o;
+                } else {
                 o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), (float)q[0], (float)q[4]), 0.0f);
                 o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), (float)q[1], (float)q[5]), 0.0f);
                 o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), (float)q[2], (float)q[6]), 0.0f);
                 o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), (float)q[3], (float)q[7]), 0.0f);
+                }
                 // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
                 // above, and the residual read of this lane's own elements precedes this write
                 *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
@@ -237,9 +256,10 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
 }
 
 // BITS: the observation arrives as the packed bitstring inv_step writes under INV_STEP_OBS_BITS (57 words per sample).
-template <bool BITS>
+// SAVE: training forward -- every layer also stores x^, its activation and rstd for k_policy_trunk_bwd.
+template <bool BITS, bool SAVE>
 __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params prm, const void *__restrict__ obs_in,
-                                                          bf16 *__restrict__ feat, int N)
+                                                          bf16 *__restrict__ feat, int N, inv_policy_saved sv)
 {
     __shared__ __attribute__((aligned(16))) bf16 tile[NPOS * CSTRIDE];         // 55 488 B: layers run in place -> 2 blocks / CU
     __shared__ float red[2 * WAVES];
@@ -322,14 +342,23 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
         // the register file allows.  At 2 x 10 the LDS reads alone need the CU's full 128 B/clk while the MFMAs
         // issue; conv3/4 use 4 row blocks x 5 pixel tiles (half the LDS traffic, each weight fragment fetched by two
         // waves), which also leaves the register allocator enough room to keep the epilogue out of scratch.
+        if (SAVE) {
+            const size_t sn = (size_t)n * P;
+            bf16 *const xh0 = reinterpret_cast<bf16 *>(sv.xhat[0]) + sn * 32, *const xh1 = reinterpret_cast<bf16 *>(sv.xhat[1]) + sn * 64;
+            bf16 *const xh2 = reinterpret_cast<bf16 *>(sv.xhat[2]) + sn * 128, *const xh3 = reinterpret_cast<bf16 *>(sv.xhat[3]) + sn * 128;
+            bf16 *const ac0 = reinterpret_cast<bf16 *>(sv.act[0]) + sn * 32, *const ac1 = reinterpret_cast<bf16 *>(sv.act[1]) + sn * 64;
+            bf16 *const ac2 = reinterpret_cast<bf16 *>(sv.act[2]) + sn * 128;
+            float *const rs = sv.rstd + (size_t)n * 4;
+            conv_ln_relu<32, 32, 1, 5, false, false, true>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0, LayerSave{ xh0, ac0, rs });
+            conv_ln_relu<32, 64, 1, 10, false, false, true>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1, LayerSave{ xh1, ac1, rs + 1 });
+            conv_ln_relu<64, 128, 4, 5, false, false, true>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2, LayerSave{ xh2, ac2, rs + 2 });
+            conv_ln_relu<128, 128, 4, 5, false, true, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3, LayerSave{ xh3, nullptr, rs + 3 });
+        } else {
         conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
-#if defined(POL_C2_MW2)
-        conv_ln_relu<32, 64, 2, 5, false, false>(prm.layer[1], tile, red, lane_i, (wave & 1) * 2, (wave >> 1) * 5, 5, stamp_prev, 1);
-#else
         conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
-#endif
         conv_ln_relu<64, 128, 4, 5, false, false>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2);
         conv_ln_relu<128, 128, 4, 5, false, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3);
+        }
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * P * 128);
         for (int q = tid; q < P * 16; q += THREADS) {
@@ -339,6 +368,320 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
         if (BITS && tid < OBS_WORDS) obw[tid] = next_word;        // every read of obw happened before the first barrier of this sample
         __syncthreads();
         STAMP(13);                                                   // feature write-out
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the trunk for the PPO update: per sample, layer 4 -> 1,
+//   dy  = da * [x^ w + b > 0]                       (ReLU mask recomputed from the saved x^)
+//   dx^ = dy * w
+//   dz  = rstd * (dx^ - mean(dx^) - x^ * mean(dx^ x^))         LayerNorm over the whole sample
+//   da' = convT(dz)  (+ dz for the residual of layer 4)         implicit GEMM with the transposed weights
+// dy and dz go to HBM (the parameter gradients are batch reductions / GEMMs over them), dz also into the LDS tile
+// as the B operand of the transposed convolution; da' stays in the accumulator registers, whose ownership is chosen
+// to equal the forward epilogue ownership of the layer below, so the next layer's LayerNorm backward runs on it in place.
+
+// GEMM core of conv_ln_relu (same fragment layouts, same software pipeline), accumulators handed back to the caller.
+template <int CIN, int COUT, int MW, int NW>
+__device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int lane, int m0, int n0, f32x4 (&acc)[MW][NW])
+{
+    constexpr int KPT = CIN / 32, KS = 9 * KPT;
+    const int c16 = lane & 15, kg = lane >> 4;
+    int tap0[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int px = (n0 + i) * 16 + c16;
+        tap0[i] = pos_of(min(px, P - 1)) * CSTRIDE - (PW + 1) * CSTRIDE + 8 * kg;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(w) + (size_t)m0 * KS * 64 + lane;
+    constexpr int AD = 3;
+    bf16x8 a[AD + 1][MW], b[NW];
+#pragma unroll
+    for (int d = 0; d < AD; ++d)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) a[d][mi] = wp[((size_t)mi * KS + (d < KS ? d : KS - 1)) * 64];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int ksn = ks + 1 < KS ? ks + 1 : ks;
+        const int ksa = ks + AD < KS ? ks + AD : KS - 1;
+        const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
+        const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSTRIDE + kcn * 32;
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi)
+                acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
+            b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
+        }
+    }
+}
+
+// LayerNorm + ReLU backward of one layer on the accumulator registers (in: da, ownership MW x NW tiles from m0 / n0).
+template <int COUT, int MW, int NW>
+__device__ __forceinline__ void ln_relu_bwd(const void *ln_packed, const bf16 *xhat_n, float rstd, bf16 *dy_n, bf16 *dz_n,
+                                            bf16 *tile, float *red, int lane, int m0, int n0, f32x4 (&acc)[MW][NW])
+{
+    const int c16 = lane & 15, kg = lane >> 4;
+    int pix[NW], base[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        pix[i] = (n0 + i) * 16 + c16;
+        base[i] = pos_of(min(pix[i], P - 1)) * CSTRIDE;
+    }
+    bf16x4 xh[MW][NW];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int ch0 = (m0 + mi) * 16 + 4 * kg;
+        f16x8 ln[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const size_t go = (size_t)min(pix[i], P - 1) * COUT + ch0;
+            ln[i] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(ln_packed) + go * 2);
+            xh[mi][i] = *reinterpret_cast<const bf16x4 *>(xhat_n + go);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const bool valid = pix[i] < P;
+            bf16x4 dyq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = (float)xh[mi][i][e], g = (float)ln[i][e];
+                const float y = fmaf(x, g, (float)ln[i][4 + e]);
+                const float d = (valid && y > 0.0f) ? acc[mi][i][e] : 0.0f;
+                const float dxh = d * g;
+                dyq[e] = (bf16)d;
+                acc[mi][i][e] = dxh;
+                s1 += dxh;
+                s2 += dxh * x;
+            }
+            if (valid) *reinterpret_cast<bf16x4 *>(dy_n + (size_t)pix[i] * COUT + ch0) = dyq;
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = s1; red[WAVES + wave] = s2; }
+    __syncthreads();                                 // also: every wave is past its reads of the tile (previous GEMM)
+    float S1 = 0.0f, S2 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { S1 += red[w]; S2 += red[WAVES + w]; }
+    const float inv_cnt = 1.0f / (float)(COUT * P);
+    const float m1 = S1 * inv_cnt, m2 = S2 * inv_cnt;
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int ch0 = (m0 + mi) * 16 + 4 * kg;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            if (pix[i] < P) {
+                bf16x4 dzq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dzq[e] = (bf16)(rstd * (acc[mi][i][e] - m1 - (float)xh[mi][i][e] * m2));
+                *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = dzq;
+                *reinterpret_cast<bf16x4 *>(dz_n + (size_t)pix[i] * COUT + ch0) = dzq;
+            }
+        }
+    }
+    __syncthreads();                                 // dz tile complete (B operand of the transposed convolution); red[] reusable
+}
+
+__global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_params prm, inv_policy_saved sv, const bf16 *__restrict__ dfeat,
+                                                              inv_policy_grads gr, int N)
+{
+    __shared__ __attribute__((aligned(16))) bf16 tile[NPOS * CSTRIDE];
+    __shared__ float red[2 * WAVES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
+    for (int i = tid; i < NPOS * CSTRIDE / 8; i += THREADS) {     // halo stays zero for the life of the block
+        bf16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
+        reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
+    }
+    __syncthreads();
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        int lane_i = lane;
+        asm volatile("" : "+v"(lane_i));             // keep per-lane addresses per-sample recomputations (see k_policy_trunk)
+        const size_t sn = (size_t)n * P;
+        const float4 rs = *reinterpret_cast<const float4 *>(sv.rstd + (size_t)n * 4);
+        const int c16 = lane_i & 15, kg = lane_i >> 4;
+        // ---- layer 4 (128 ch, 4 x 5 ownership): da = dfeat
+        {
+            f32x4 acc[4][5];
+            const int m0 = (wave & 1) * 4, n0 = (wave >> 1) * 5;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int px = min((n0 + i) * 16 + c16, P - 1);
+                    const bf16x4 v = *reinterpret_cast<const bf16x4 *>(dfeat + (sn + px) * 128 + (m0 + mi) * 16 + 4 * kg);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mi][i][e] = (float)v[e];
+                }
+            ln_relu_bwd<128, 4, 5>(prm.ln[3], reinterpret_cast<const bf16 *>(sv.xhat[3]) + sn * 128, rs.w,
+                                   reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128,
+                                   tile, red, lane_i, m0, n0, acc);
+            // da3 = convT4(dz4) + dz4 (residual: z4 = conv4(a3) + b4 + a3), same 4 x 5 ownership as layer 3's epilogue
+            f32x4 nxt[4][5];
+            conv_gemm<128, 128, 4, 5>(prm.wt[2], tile, lane_i, m0, n0, nxt);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int px = min((n0 + i) * 16 + c16, P - 1);
+                    const bf16x4 r = *reinterpret_cast<const bf16x4 *>(tile + pos_of(px) * CSTRIDE + (m0 + mi) * 16 + 4 * kg);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nxt[mi][i][e] += (float)r[e];
+                }
+            // ---- layer 3 (128 ch)
+            ln_relu_bwd<128, 4, 5>(prm.ln[2], reinterpret_cast<const bf16 *>(sv.xhat[2]) + sn * 128, rs.z,
+                                   reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128,
+                                   tile, red, lane_i, m0, n0, nxt);
+        }
+        // ---- layer 2 (64 ch, 1 x 10 ownership): da2 = convT3(dz3)
+        {
+            f32x4 acc[1][10];
+            conv_gemm<128, 64, 1, 10>(prm.wt[1], tile, lane_i, wave, 0, acc);
+            ln_relu_bwd<64, 1, 10>(prm.ln[1], reinterpret_cast<const bf16 *>(sv.xhat[1]) + sn * 64, rs.y,
+                                   reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64, reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64,
+                                   tile, red, lane_i, wave, 0, acc);
+        }
+        // ---- layer 1 (32 ch, 1 x 5 ownership): da1 = convT2(dz2); no data gradient below (the observation)
+        {
+            f32x4 acc[1][5];
+            conv_gemm<64, 32, 1, 5>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5, acc);
+            ln_relu_bwd<32, 1, 5>(prm.ln[0], reinterpret_cast<const bf16 *>(sv.xhat[0]) + sn * 32, rs.x,
+                                  reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32, reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32,
+                                  tile, red, lane_i, wave & 1, (wave >> 1) * 5, acc);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of one convolution:  dW[co][tap][ci] = sum_n sum_p dz[n][p][co] * x[n][p + tap][ci].
+// The contraction runs over PIXELS, the strided dimension of the channels-last tensors, so both MFMA operands are
+// fetched with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns and each
+// lane receives one column): rows = pixels (k), columns = channels (m for dz, n for x).  Every lane supplies its own row
+// address, so the zero-haloed tile of the forward kernel serves all nine taps (row = position + tap offset).
+// Block = 8 waves; wave (mslot, nb) accumulates MWW x 9 tiles  D[16 co][16 ci] of its channel block nb for all taps over
+// the block's share of the samples, then adds them into dW with f32 atomics.  K = 150 pixels padded to 160 (5 k-steps;
+// the padding rows of the dz tile are zero).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16 *row_lo, const bf16 *row_hi)
+{
+    // rows k = 8g + q (lo) and 8g + 4 + q (hi) of the k-step, 4 consecutive columns at this lane's address
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(row_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(row_hi));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int WG_THREADS = 512, WG_WAVES = 8, KPAD = 160;
+
+template <int CINP, int COUT, int MWW, int NBW>
+__global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restrict__ x, const bf16 *__restrict__ dz, float *__restrict__ dw, int N)
+{
+    constexpr int MSLOTS = WG_WAVES / NBW, MS = MWW * MSLOTS;            // m-blocks (16 channels) per block
+    constexpr int MBLOCKS = COUT / 16, Q = (MBLOCKS + MS - 1) / MS;       // output slices (blockIdx.x % Q)
+    constexpr int DCH = MS * 16, DSTRIDE = DCH + 8;                      // dz tile: [160][DCH] bf16, 16-B row pad
+    constexpr int XSTRIDE = CINP + 8;                                    // x tile:  [204 positions][CINP] bf16, zero halo
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
+    bf16 *const dzt = reinterpret_cast<bf16 *>(wg_lds);
+    bf16 *const xt = dzt + KPAD * DSTRIDE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
+    const int mslot = wave / NBW, nb = wave % NBW;
+    const int slice = blockIdx.x % Q, sidx = blockIdx.x / Q, nslices = gridDim.x / Q;
+    const int co_base = slice * DCH;                                     // first output channel of this block
+    const int mb0 = mslot * MWW;                                         // wave's first m-block inside the slice
+    const bool active = co_base + (mb0 + MWW) * 16 <= COUT;              // wave-uniform (layer 1: 2 of 8 m-slots exist)
+
+    for (int i = tid; i < (KPAD * DSTRIDE + NPOS * XSTRIDE) / 8; i += WG_THREADS) {
+        bf16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
+        reinterpret_cast<bf16x8 *>(dzt)[i] = z;
+    }
+    f32x4 acc[MWW][9];
+#pragma unroll
+    for (int mi = 0; mi < MWW; ++mi)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][t][e] = 0.0f;
+
+    // per-lane row addresses of the transposing reads: lane 4q + p of group g -> row 8g + 4h + q, columns 4p .. 4p+3
+    const int g = lane >> 4, q = (lane >> 2) & 3, p4 = (lane & 3) * 4;
+    int xrow[5][2];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pk = 32 * ks + 8 * g + 4 * h + q;                  // pixel of this k row; >= 150: the dz row is zero
+            xrow[ks][h] = (pos_of(min(pk, P - 1)) - (PW + 1)) * XSTRIDE + nb * 16 + p4;
+        }
+    const int arow = (8 * g + q) * DSTRIDE + mb0 * 16 + p4;
+
+    constexpr int DZ_CHUNKS = DCH / 8, X_CHUNKS = CINP / 8;              // 16-byte chunks per pixel row
+    const int dcols = min(DCH, COUT - co_base);                          // channels of the slice that exist
+    for (int n = sidx; n < N; n += nslices) {
+        __syncthreads();                                                 // previous sample's reads are done (and the zero fill)
+        const bf16 *dzn = dz + (size_t)n * P * COUT + co_base;
+        for (int c = tid; c < P * DZ_CHUNKS; c += WG_THREADS) {
+            const int px = c / DZ_CHUNKS, part = c - px * DZ_CHUNKS;
+            if (part * 8 < dcols)
+                *reinterpret_cast<bf16x8 *>(dzt + px * DSTRIDE + part * 8) = *reinterpret_cast<const bf16x8 *>(dzn + (size_t)px * COUT + part * 8);
+        }
+        const bf16 *xn = x + (size_t)n * P * CINP;
+        for (int c = tid; c < P * X_CHUNKS; c += WG_THREADS) {
+            const int px = c / X_CHUNKS, part = c - px * X_CHUNKS;
+            *reinterpret_cast<bf16x8 *>(xt + pos_of(px) * XSTRIDE + part * 8) = *reinterpret_cast<const bf16x8 *>(xn + (size_t)px * CINP + part * 8);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                bf16x8 a[MWW];
+#pragma unroll
+                for (int mi = 0; mi < MWW; ++mi)
+                    a[mi] = tr_frag(dzt + arow + (32 * ks) * DSTRIDE + mi * 16, dzt + arow + (32 * ks + 4) * DSTRIDE + mi * 16);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int toff = ((t / 3) * PW + (t % 3)) * XSTRIDE;
+                    const bf16x8 b = tr_frag(xt + xrow[ks][0] + toff, xt + xrow[ks][1] + toff);
+#pragma unroll
+                    for (int mi = 0; mi < MWW; ++mi)
+                        acc[mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b, acc[mi][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (active) {
+        const int r = lane & 15;
+#pragma unroll
+        for (int mi = 0; mi < MWW; ++mi)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = co_base + (mb0 + mi) * 16 + 4 * g + e;
+                    atomicAdd(dw + ((size_t)co * 9 + t) * CINP + nb * 16 + r, acc[mi][t][e]);
+                }
     }
 }
 
@@ -356,25 +699,37 @@ extern "C" int inv_policy_debug_stamps(unsigned long long *out16_host, int reset
 }
 #endif
 
-static int launch_trunk(const inv_policy_params *params, const void *obs, bool bits, void *feat_bf16, int32_t N, void *stream)
+static int trunk_grid(int N)
 {
-    if (!params || !obs || !feat_bf16 || N < 0) return INV_ERR_BAD_ARG;
-    if (N == 0) return INV_OK;
-    for (int l = 0; l < 4; ++l)
-        if (!params->layer[l].w || !params->layer[l].bias || !params->layer[l].ln) return INV_ERR_BAD_ARG;
     static int cus = 0;                              // CU count, queried once (not in a captured region)
     if (cus == 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
         else cus = 256;
     }
-    const int grid = N < 2 * cus ? N : 2 * cus;     // two resident 256-thread workgroups per CU (55 KB of LDS each), persistent over samples
+    return N < 2 * cus ? N : 2 * cus;               // two resident 256-thread workgroups per CU (55 KB of LDS each), persistent over samples
+}
+
+static bool layers_ok(const inv_policy_params *params)
+{
+    for (int l = 0; l < 4; ++l)
+        if (!params->layer[l].w || !params->layer[l].bias || !params->layer[l].ln) return false;
+    return true;
+}
+
+static int launch_trunk(const inv_policy_params *params, const void *obs, bool bits, void *feat_bf16, int32_t N, void *stream)
+{
+    if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params)) return INV_ERR_BAD_ARG;
+    if (N == 0) return INV_OK;
+    const int grid = trunk_grid(N);
+    inv_policy_saved none;
+    memset(&none, 0, sizeof none);
     if (bits)
-        hipLaunchKernelGGL(pol::k_policy_trunk<true>, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
-                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N);
+        hipLaunchKernelGGL((pol::k_policy_trunk<true, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, none);
     else
-        hipLaunchKernelGGL(pol::k_policy_trunk<false>, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
-                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N);
+        hipLaunchKernelGGL((pol::k_policy_trunk<false, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, none);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }
 
@@ -386,4 +741,71 @@ extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *ob
 extern "C" int inv_policy_trunk_bits(const inv_policy_params *params, const uint32_t *bits, void *feat_bf16, int32_t N, void *stream)
 {
     return launch_trunk(params, bits, true, feat_bf16, N, stream);
+}
+
+static bool saved_ok(const inv_policy_saved *sv)
+{
+    if (!sv || !sv->rstd) return false;
+    for (int l = 0; l < 4; ++l)
+        if (!sv->xhat[l] || (l < 3 && !sv->act[l])) return false;
+    return true;
+}
+
+extern "C" int inv_policy_trunk_train_fwd(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, void *feat_bf16,
+                                          const inv_policy_saved *saved, int32_t N, void *stream)
+{
+    if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params) || !saved_ok(saved)) return INV_ERR_BAD_ARG;
+    if (N == 0) return INV_OK;
+    const int grid = trunk_grid(N);
+    if (obs_is_bits)
+        hipLaunchKernelGGL((pol::k_policy_trunk<true, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, *saved);
+    else
+        hipLaunchKernelGGL((pol::k_policy_trunk<false, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, *saved);
+    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+}
+
+extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const inv_policy_saved *saved, const void *dfeat_bf16,
+                                    const inv_policy_grads *grads, int32_t N, void *stream)
+{
+    if (!params || !dfeat_bf16 || !grads || N < 0 || !saved_ok(saved)) return INV_ERR_BAD_ARG;
+    for (int l = 0; l < 4; ++l)
+        if (!params->ln[l] || !grads->dy[l] || !grads->dz[l] || (l < 3 && !params->wt[l])) return INV_ERR_BAD_ARG;
+    if (N == 0) return INV_OK;
+    hipLaunchKernelGGL(pol::k_policy_trunk_bwd, dim3(trunk_grid(N)), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, *saved,
+                       reinterpret_cast<const pol::bf16 *>(dfeat_bf16), *grads, (int)N);
+    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+}
+
+template <int CINP, int COUT, int MWW, int NBW>
+static int launch_wgrad(const void *x, const void *dz, float *dw, int N, hipStream_t st)
+{
+    constexpr int MS = MWW * (pol::WG_WAVES / NBW), Q = (COUT / 16 + MS - 1) / MS;
+    constexpr int DSTRIDE = MS * 16 + 8, XSTRIDE = CINP + 8;
+    constexpr size_t lds = (size_t)(pol::KPAD * DSTRIDE + pol::NPOS * XSTRIDE) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_wgrad<CINP, COUT, MWW, NBW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return INV_ERR_HIP;
+        attr_set = true;
+    }
+    const int per_slice = trunk_grid(N) / Q > 0 ? trunk_grid(N) / Q : 1;             // two 8-wave blocks per CU (<= 126 VGPRs, <= 68 KB LDS)
+    const int nslices = N < per_slice ? N : per_slice;
+    hipLaunchKernelGGL((pol::k_policy_wgrad<CINP, COUT, MWW, NBW>), dim3(nslices * Q), dim3(pol::WG_THREADS), lds, st,
+                       reinterpret_cast<const pol::bf16 *>(x), reinterpret_cast<const pol::bf16 *>(dz), dw, N);
+    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+}
+
+extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, int32_t N, void *stream)
+{
+    if (!x_bf16 || !dz_bf16 || !dw || N < 0 || layer < 0 || layer > 3) return INV_ERR_BAD_ARG;
+    if (N == 0) return INV_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (layer) {
+    case 0: return launch_wgrad<16, 32, 1, 1>(x_bf16, dz_bf16, dw, N, st);
+    case 1: return launch_wgrad<32, 64, 1, 2>(x_bf16, dz_bf16, dw, N, st);
+    case 2: return launch_wgrad<64, 128, 2, 4>(x_bf16, dz_bf16, dw, N, st);
+    default: return launch_wgrad<128, 128, 2, 8>(x_bf16, dz_bf16, dw, N, st);
+    }
 }

@@ -1,0 +1,190 @@
+"""Training path of InversusCNNPolicy through the fused trunk kernels.
+
+`FusedTrainPolicy(policy)(grid, extra)` returns the same (logits, value) as the module and is differentiable
+with respect to the module's parameters, but the convolutional trunk (policies.py:91-99) runs as
+
+  forward   csrc/inv_policy.hip  k_policy_trunk<.., SAVE>   one kernel, activations in LDS, keeps x^ / act / rstd
+  backward  csrc/inv_policy.hip  k_policy_trunk_bwd         one kernel: LayerNorm + ReLU backward and the data
+                                                            gradient of the convolutions (transposed implicit GEMMs)
+
+and the parameter gradients are batch reductions over the tensors that kernel writes (dy, dz; channels-last bf16):
+LayerNorm weight / bias and conv bias as sums, conv weights as one im2col GEMM per layer (hipBLASLt through torch).
+The two MLP heads stay in torch autograd; their 19 200-column first layer runs in bf16 on the kernel's feature order.
+
+Numerics: bf16 operands with f32 accumulation, like `PPOAgent(update_autocast=torch.bfloat16)` -- gradients agree with
+the f32 module to ~1e-2 relative (tests/test_gpu_fused_train.py), not bit for bit.  Only the 12 x 10 x 15 observation.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from .device_env import unpack_obs
+from .fused_policy import _CIN_PAD, _pack_conv
+
+_COUT = (32, 64, 128, 128)
+_CIN = (12, 32, 64, 128)
+_CINP = (16, 32, 64, 128)          # channels of the wgrad kernel's x operand (layer 1: 12 planes + 4 zero channels)
+_WGRAD_CHUNK = 2048            # samples per im2col GEMM (bounds the 9x-expanded operand to ~0.7 GB)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _pack_ln(weight, bias, cout):
+    """LayerNorm([C,10,15]) affine -> fp16 [150][C/4][weight x4 | bias x4] (see inversus_hip.h)."""
+    w = weight.detach().float().reshape(cout, 150).t().reshape(150, cout // 4, 4)
+    b = bias.detach().float().reshape(cout, 150).t().reshape(150, cout // 4, 4)
+    return torch.cat([w, b], dim=2).contiguous().to(torch.float16)
+
+
+def _wgrad_torch(x, dz, cin, cout):
+    """dW[co][ci][ky][kx] = sum_n sum_p dz[n][p][co] * x[n][p + (ky-1, kx-1)][ci] as chunked im2col GEMMs in torch --
+    the cross-check of the HIP kernel (tests), not the training path.  x: bf16 [N,150,>=cin], dz: bf16 [N,150,cout]."""
+    x = x[..., :cin]
+    n_all = x.shape[0]
+    out = torch.zeros(cout, 9 * cin, dtype=torch.float32, device=x.device)
+    for lo in range(0, n_all, _WGRAD_CHUNK):
+        xs, ds = x[lo:lo + _WGRAD_CHUNK], dz[lo:lo + _WGRAD_CHUNK]
+        n = xs.shape[0]
+        xp = F.pad(xs.reshape(n, 10, 15, cin), (0, 0, 1, 1, 1, 1))                        # zero halo: [n,12,17,cin]
+        cols = xp.unfold(1, 3, 1).unfold(2, 3, 1)                                         # [n,10,15,cin,ky,kx]
+        cols = cols.permute(0, 1, 2, 4, 5, 3).reshape(n * 150, 9 * cin)                   # k = (ky, kx, ci)
+        out += (ds.reshape(n * 150, cout).t() @ cols).float()
+    return out.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+
+
+def _wgrad(layer, x, dz):
+    """Weight gradient of conv `layer` through inv_policy_wgrad (MFMA over pixels, transposing LDS reads).
+    x: bf16 [N,150,CinP] contiguous layer input, dz: bf16 [N,150,Cout] -> f32 [Cout, Cin, 3, 3]."""
+    lib = L.load()
+    cin, cinp, cout = _CIN[layer], _CINP[layer], _COUT[layer]
+    assert x.dtype == dz.dtype == torch.bfloat16 and x.is_contiguous() and dz.is_contiguous()
+    assert tuple(x.shape[1:]) == (150, cinp) and tuple(dz.shape[1:]) == (150, cout)
+    dw = torch.zeros((cout, 9, cinp), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.inv_policy_wgrad(layer, _ptr(x), _ptr(dz), _ptr(dw), x.shape[0],
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    L.raise_for(rc, lib)
+    return dw[:, :, :cin].reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+
+
+class _TrunkTrainFn(torch.autograd.Function):
+    """features = trunk(obs; conv / LayerNorm parameters of the four layers); obs f32 planes or packed int32."""
+
+    @staticmethod
+    def forward(ctx, obs, *params):
+        lib = L.load()
+        dev = obs.device
+        n = obs.shape[0]
+        bits = obs.dtype == torch.int32
+        obs = obs.contiguous() if bits else obs.contiguous().float()
+        keep, fwd = [], L.InvPolicyParams()
+        lns = []
+        for i in range(4):
+            w, b, g, e = params[4 * i:4 * i + 4]
+            wp = _pack_conv(w.detach().float(), _CIN_PAD[i])
+            bp = b.detach().float().contiguous()
+            ln = _pack_ln(g, e, _COUT[i])
+            keep += [wp, bp, ln]
+            lns.append(ln)
+            fwd.layer[i] = L.InvPolicyLayer(wp.data_ptr(), bp.data_ptr(), ln.data_ptr())
+        xhat = [torch.empty((n, 150, c), dtype=torch.bfloat16, device=dev) for c in _COUT]
+        act = [torch.empty((n, 150, c), dtype=torch.bfloat16, device=dev) for c in _COUT[:3]]
+        rstd = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        feat = torch.empty((n, 19200), dtype=torch.bfloat16, device=dev)
+        saved = L.InvPolicySaved()
+        for i in range(4):
+            saved.xhat[i] = xhat[i].data_ptr()
+        for i in range(3):
+            saved.act[i] = act[i].data_ptr()
+        saved.rstd = rstd.data_ptr()
+        with torch.cuda.device(dev):
+            rc = lib.inv_policy_trunk_train_fwd(C.byref(fwd), _ptr(obs), 1 if bits else 0, _ptr(feat), C.byref(saved), n,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.raise_for(rc, lib)
+        ctx.save_for_backward(obs, rstd, *xhat, *act, *lns, *[params[4 * i] for i in range(4)])
+        ctx.bits = bits
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = L.load()
+        sv = ctx.saved_tensors
+        obs, rstd = sv[0], sv[1]
+        xhat, act, lns, ws = sv[2:6], sv[6:9], sv[9:13], sv[13:17]
+        dev, n = obs.device, obs.shape[0]
+        dfeat = dfeat.contiguous().to(torch.bfloat16)
+        dy = [torch.empty_like(t) for t in xhat]
+        dz = [torch.empty_like(t) for t in xhat]
+        bp, keep = L.InvPolicyBwdParams(), []
+        for i in range(1, 4):                       # Wt[ci][8 - tap][co] = W[co][ci][tap], packed as a conv with Cin = Cout_i
+            wt = ws[i].detach().float().flip(2, 3).permute(1, 0, 2, 3).contiguous()
+            pk = _pack_conv(wt, _COUT[i])
+            keep.append(pk)
+            bp.wt[i - 1] = pk.data_ptr()
+        for i in range(4):
+            bp.ln[i] = lns[i].data_ptr()
+        saved, grads = L.InvPolicySaved(), L.InvPolicyGrads()
+        for i in range(4):
+            saved.xhat[i] = xhat[i].data_ptr()
+            grads.dy[i] = dy[i].data_ptr()
+            grads.dz[i] = dz[i].data_ptr()
+        for i in range(3):
+            saved.act[i] = act[i].data_ptr()
+        saved.rstd = rstd.data_ptr()
+        with torch.cuda.device(dev):
+            rc = lib.inv_policy_trunk_bwd(C.byref(bp), C.byref(saved), _ptr(dfeat), C.byref(grads), n,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.raise_for(rc, lib)
+        planes = unpack_obs(obs) if ctx.bits else obs
+        x0 = torch.zeros((n, 150, 16), dtype=torch.bfloat16, device=dev)              # channels-last layer-1 input, 12 -> 16 channels
+        x0[:, :, :12] = planes.reshape(n, 12, 150).permute(0, 2, 1)
+        out = [None]
+        for i in range(4):
+            c = _COUT[i]
+            x_in = x0 if i == 0 else act[i - 1]
+            dw = _wgrad(i, x_in, dz[i])
+            db = dz[i].sum(dim=(0, 1), dtype=torch.float32)
+            dg = (dy[i] * xhat[i]).sum(dim=0, dtype=torch.float32).t().reshape(c, 10, 15)
+            de = dy[i].sum(dim=0, dtype=torch.float32).t().reshape(c, 10, 15)
+            out += [dw, db, dg, de]
+        return tuple(out)
+
+
+def _trunk_params(p):
+    out = []
+    for conv, norm in ((p.conv1, p.norm1), (p.conv2, p.norm2), (p.conv3, p.norm3), (p.conv4, p.norm4)):
+        out += [conv.weight, conv.bias, norm.weight, norm.bias]
+    return out
+
+
+class FusedTrainPolicy:
+    """Differentiable stand-in for `policy(grid, extra)` in the PPO update: fused trunk forward / backward kernels,
+    torch heads.  `grid`: f32 planes [B,12,10,15] or the packed int32 observations [B,57]."""
+
+    def __init__(self, policy):
+        p = policy
+        if tuple(p.norm1.normalized_shape) != (32, 10, 15) or p.conv1.in_channels != 12:
+            raise ValueError("the fused trunk supports the reference's 12 x 10 x 15 observation only")
+        if p.conv1.weight.device.type != "cuda":
+            raise RuntimeError("FusedTrainPolicy needs the policy on the GPU")
+        self.policy = policy
+        L.load()
+
+    def features(self, grid):
+        return _TrunkTrainFn.apply(grid, *_trunk_params(self.policy))
+
+    def __call__(self, grid, extra):
+        p = self.policy
+        feat = self.features(grid)                                                     # bf16 [B, 19200], index pixel*128 + c
+        extra = extra.float()
+        outs = []
+        for fc in (p.fc_actor, p.fc_critic):
+            w = fc[0].weight                                                           # [256, 19204], columns c*150 + pixel
+            wf = w[:, :19200].reshape(-1, 128, 150).permute(0, 2, 1).reshape(-1, 19200).to(torch.bfloat16)
+            h = (feat @ wf.t()).float() + extra @ w[:, 19200:].t() + fc[0].bias
+            outs.append(fc[4](torch.relu(fc[2](torch.relu(h)))))
+        return outs[0], outs[1]
