@@ -222,6 +222,12 @@ int  inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const inv_policy_
  * [N][150][CinP] with CinP = 16, 32, 64, 128 (layer 0: the 12 observation planes padded with 4 zero channels);
  * dz: what inv_policy_trunk_bwd wrote.  MFMA over pixels through transposing LDS reads. */
 int  inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, int32_t N, void *stream);
+/* Batch reductions for the LayerNorm / bias gradients of one layer, one pass over dy, xhat, dz (bf16 [N][E], E = 150 * C):
+ * partial[s][0][e] = sum dy*xhat, partial[s][1][e] = sum dy, partial[s][2][e] = sum dz over the samples n = s (mod slices);
+ * f32 [slices][3][E], every entry written.  Adding the slices gives the LayerNorm weight / bias gradients in
+ * [pixel][channel] order and (summed over pixels) the conv bias gradient. */
+int  inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, const void *dz_bf16, float *partial, int32_t slices,
+                            int32_t elems_per_sample, int32_t N, void *stream);
 
 #ifdef __cplusplus
 }

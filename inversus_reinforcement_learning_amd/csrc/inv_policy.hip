@@ -685,6 +685,45 @@ __global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Batch reductions behind the LayerNorm / bias gradients: for every element e of a layer's [150][C] map
+//   g_w[e] = sum_n dy[n][e] * xhat[n][e]      g_b[e] = sum_n dy[n][e]      g_z[e] = sum_n dz[n][e]
+// (conv bias gradient = g_z summed over the 150 pixels by the caller).  One pass over the three bf16 tensors: a thread
+// owns 8 consecutive channels (16-byte loads), blockIdx.y strides over the samples and writes its partial sums to
+// part[slice][3][E]; the caller adds the slices.
+__global__ __launch_bounds__(256) void k_policy_param_grads(const bf16 *__restrict__ dy, const bf16 *__restrict__ xhat, const bf16 *__restrict__ dz,
+                                                        float *__restrict__ part, int E8, int N)
+{
+    const int e8 = blockIdx.x * 256 + threadIdx.x;
+    if (e8 >= E8) return;
+    float aw[8], ab[8], az[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aw[j] = ab[j] = az[j] = 0.0f;
+    const size_t stride = (size_t)E8 * 8;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const size_t o = (size_t)n * stride + (size_t)e8 * 8;
+        const bf16x8 d = *reinterpret_cast<const bf16x8 *>(dy + o);
+        const bf16x8 x = *reinterpret_cast<const bf16x8 *>(xhat + o);
+        const bf16x8 z = *reinterpret_cast<const bf16x8 *>(dz + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float df = (float)d[j];
+            aw[j] = fmaf(df, (float)x[j], aw[j]);
+            ab[j] += df;
+            az[j] += (float)z[j];
+        }
+    }
+    // partial sums of this sample slice, [slice][3][E]: no atomics (they would all land on the same 3 E addresses)
+    float *o = part + (size_t)blockIdx.y * 3 * stride + (size_t)e8 * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(aw[0], aw[1], aw[2], aw[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(aw[4], aw[5], aw[6], aw[7]);
+    *reinterpret_cast<float4 *>(o + stride) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+    *reinterpret_cast<float4 *>(o + stride + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
+    *reinterpret_cast<float4 *>(o + 2 * stride) = make_float4(az[0], az[1], az[2], az[3]);
+    *reinterpret_cast<float4 *>(o + 2 * stride + 4) = make_float4(az[4], az[5], az[6], az[7]);
+}
+
 }  // namespace pol
 
 #ifdef INV_POLICY_STAMPS
@@ -808,4 +847,14 @@ extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *d
     case 2: return launch_wgrad<64, 128, 2, 4>(x_bf16, dz_bf16, dw, N, st);
     default: return launch_wgrad<128, 128, 2, 8>(x_bf16, dz_bf16, dw, N, st);
     }
+}
+
+extern "C" int inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, const void *dz_bf16, float *partial, int32_t slices,
+                                      int32_t elems_per_sample, int32_t N, void *stream)
+{
+    if (!dy_bf16 || !xhat_bf16 || !dz_bf16 || !partial || N < 0 || slices < 1 || elems_per_sample <= 0 || (elems_per_sample & 7)) return INV_ERR_BAD_ARG;
+    const int e8 = elems_per_sample / 8, bx = (e8 + 255) / 256;
+    hipLaunchKernelGGL(pol::k_policy_param_grads, dim3(bx, slices), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const pol::bf16 *>(dy_bf16),
+                       reinterpret_cast<const pol::bf16 *>(xhat_bf16), reinterpret_cast<const pol::bf16 *>(dz_bf16), partial, e8, (int)N);
+    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }

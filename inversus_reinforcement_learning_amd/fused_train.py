@@ -8,7 +8,8 @@ with respect to the module's parameters, but the convolutional trunk (policies.p
                                                             gradient of the convolutions (transposed implicit GEMMs)
 
 and the parameter gradients are batch reductions over the tensors that kernel writes (dy, dz; channels-last bf16):
-LayerNorm weight / bias and conv bias as sums, conv weights as one im2col GEMM per layer (hipBLASLt through torch).
+LayerNorm weight / bias and conv bias by one reduction kernel per layer (k_policy_param_grads), conv weights by
+k_policy_wgrad (MFMA over pixels through transposing LDS reads).
 The two MLP heads stay in torch autograd; their 19 200-column first layer runs in bf16 on the kernel's feature order.
 
 Numerics: bf16 operands with f32 accumulation, like `PPOAgent(update_autocast=torch.bfloat16)` -- gradients agree with
@@ -26,6 +27,7 @@ from .fused_policy import _CIN_PAD, _pack_conv
 _COUT = (32, 64, 128, 128)
 _CIN = (12, 32, 64, 128)
 _CINP = (16, 32, 64, 128)          # channels of the wgrad kernel's x operand (layer 1: 12 planes + 4 zero channels)
+_RED_SLICES = 128               # sample slices of the LayerNorm / bias gradient reduction (partials summed by torch)
 _WGRAD_CHUNK = 2048            # samples per im2col GEMM (bounds the 9x-expanded operand to ~0.7 GB)
 
 
@@ -147,9 +149,14 @@ class _TrunkTrainFn(torch.autograd.Function):
             c = _COUT[i]
             x_in = x0 if i == 0 else act[i - 1]
             dw = _wgrad(i, x_in, dz[i])
-            db = dz[i].sum(dim=(0, 1), dtype=torch.float32)
-            dg = (dy[i] * xhat[i]).sum(dim=0, dtype=torch.float32).t().reshape(c, 10, 15)
-            de = dy[i].sum(dim=0, dtype=torch.float32).t().reshape(c, 10, 15)
+            slices = max(1, min(n, _RED_SLICES))
+            part = torch.empty((slices, 3, 150, c), dtype=torch.float32, device=dev)       # per-slice sums of dy*x^, dy, dz
+            with torch.cuda.device(dev):
+                rc = lib.inv_policy_param_grads(_ptr(dy[i]), _ptr(xhat[i]), _ptr(dz[i]), _ptr(part), slices, 150 * c, n,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            L.raise_for(rc, lib)
+            red = part.sum(dim=0)
+            dg, de, db = red[0].t().reshape(c, 10, 15), red[1].t().reshape(c, 10, 15), red[2].sum(dim=0)
             out += [dw, db, dg, de]
         return tuple(out)
 

@@ -111,6 +111,24 @@ def test_wgrad_kernel_matches_im2col_gemm(n):
         assert float((got - want).abs().max()) < 1e-3 * max(1.0, float(want.abs().max())), layer
 
 
+def test_param_grad_reductions_match_torch():
+    import ctypes as C
+    import torch
+    from inversus_reinforcement_learning_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(0)
+    for n, c in ((1, 32), (77, 64), (900, 128)):
+        dy, xh, dz = [(torch.randn(n, 150, c, device="cuda") * s).to(torch.bfloat16) for s in (0.1, 1.0, 0.05)]
+        slices = min(n, 16)
+        part = torch.full((slices, 3, 150, c), float("nan"), device="cuda")
+        rc = lib.inv_policy_param_grads(*[C.c_void_p(t.data_ptr()) for t in (dy, xh, dz, part)], slices, 150 * c, n,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        red = part.sum(0)
+        want = torch.stack([(dy.float() * xh.float()).sum(0), dy.float().sum(0), dz.float().sum(0)])
+        assert rel(red, want) < 1e-5 and float((red - want).abs().max()) < 1e-3
+
+
 def test_ppo_update_with_fused_trunk_tracks_torch_update():
     """One PPO epoch through PPOAgent(fused_update=True) moves the parameters like the torch update does."""
     import torch
