@@ -176,6 +176,27 @@ def side_measurements(torch, np, n):
             agent.reset_buffers()
         return res
     guard("policy in the loop (selfplay, fused bf16 trunk, 2 forwards/step)", policy_cfg)
+
+    def update_cfg():
+        """PPO update over a packed self-play rollout, trunk forward/backward in the fused kernels (fused_update=True)."""
+        from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+        from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+        from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+        from inversus_reinforcement_learning_amd.training import RolloutCollector
+        torch.manual_seed(0)
+        b = DeviceEnvBatch(n, opponent="selfplay")
+        b.seed(np.arange(n, dtype=np.int64)); b.reset()
+        agent = PPOAgent(InversusCNNPolicy(12, H, W, 4), fused_act=True, fused_update=True, batch_size=n, epochs=1)
+        col = RolloutCollector(b, agent, FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval()))
+        T = 8
+        col.collect(T); agent.update()                                     # warm-up (allocator, GEMM heuristics)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        col.collect(T); torch.cuda.synchronize(); t1 = time.perf_counter()
+        agent.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        return {"rollout_steps": T, "minibatch": n, "collect_ms": round((t1 - t0) * 1e3, 1), "update_ms": round((t2 - t1) * 1e3, 1),
+                "update_ms_per_minibatch": round((t2 - t1) * 1e3 / T, 2), "update_samples_per_s": round(T * n / (t2 - t1)),
+                "train_env_steps_per_s_1_epoch": round(T * n / (t2 - t0))}
+    guard("PPO iteration (selfplay, packed obs, fused act + fused update, 1 epoch, minibatch = 16384)", update_cfg)
     return out
 
 

@@ -188,10 +188,13 @@ class FusedTrainPolicy:
         p = self.policy
         feat = self.features(grid)                                                     # bf16 [B, 19200], index pixel*128 + c
         extra = extra.float()
-        outs = []
-        for fc in (p.fc_actor, p.fc_critic):
-            w = fc[0].weight                                                           # [256, 19204], columns c*150 + pixel
-            wf = w[:, :19200].reshape(-1, 128, 150).permute(0, 2, 1).reshape(-1, 19200).to(torch.bfloat16)
-            h = (feat @ wf.t()).float() + extra @ w[:, 19200:].t() + fc[0].bias
-            outs.append(fc[4](torch.relu(fc[2](torch.relu(h)))))
-        return outs[0], outs[1]
+        # first Linear of both heads as ONE [512 x 19200] bf16 GEMM on the kernel's feature order (columns permuted from
+        # the module's c*150 + pixel to pixel*128 + c); autograd splits the gradient back onto the two weight tensors
+        w = torch.cat([p.fc_actor[0].weight, p.fc_critic[0].weight])                    # [512, 19204]
+        b = torch.cat([p.fc_actor[0].bias, p.fc_critic[0].bias])
+        hid = p.fc_actor[0].out_features
+        wf = w[:, :19200].reshape(-1, 128, 150).permute(0, 2, 1).reshape(-1, 19200).to(torch.bfloat16)
+        h = torch.relu((feat @ wf.t()).float() + extra @ w[:, 19200:].t() + b)
+        logits = p.fc_actor[4](torch.relu(p.fc_actor[2](h[:, :hid])))
+        value = p.fc_critic[4](torch.relu(p.fc_critic[2](h[:, hid:])))
+        return logits, value

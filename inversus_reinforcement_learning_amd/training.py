@@ -193,11 +193,21 @@ def main(argv=None):
     ap.add_argument("--opponent_difficulty", choices=["easy", "hard"], default="easy")
     ap.add_argument("--load_model", type=str, default=None)
     ap.add_argument("--seed", type=int, default=None)
+    # not in the reference: the fused MI355X paths and the PPO settings that make sense at thousands of envs
+    ap.add_argument("--fused", action="store_true",
+                    help="rollout forwards AND the PPO update's trunk forward/backward in the fused bf16 HIP kernels")
+    ap.add_argument("--batch_size", type=int, default=None, help="PPO minibatch size (reference default 512)")
+    ap.add_argument("--epochs", type=int, default=None, help="PPO epochs per rollout (reference default 4)")
+    ap.add_argument("--lr", type=float, default=None)
     args = ap.parse_args(argv)
     log_dir = args.log_dir or f"runs/inversus_{args.mode}"
+    kw = {k: v for k, v in (("batch_size", args.batch_size), ("epochs", args.epochs), ("lr", args.lr)) if v is not None}
+    if args.fused:
+        kw.update(fused_act=True, fused_update=True)
     if args.mode == "vs_dummy":
-        return train_vs_dummy(args.num_envs, args.total_steps, log_dir, args.opponent_difficulty, args.load_model, seed=args.seed)
-    return train_selfplay(args.num_envs, args.total_steps, log_dir, args.load_model, seed=args.seed)
+        return train_vs_dummy(args.num_envs, args.total_steps, log_dir, args.opponent_difficulty, args.load_model, seed=args.seed,
+                              agent_kwargs=kw)
+    return train_selfplay(args.num_envs, args.total_steps, log_dir, args.load_model, seed=args.seed, agent_kwargs=kw)
 
 
 if __name__ == "__main__":
