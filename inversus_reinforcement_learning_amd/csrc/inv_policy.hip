@@ -7,18 +7,20 @@
 // Why: with PyTorch-ROCm the trunk is 4 convs + 4 LayerNorm + 4 ReLU passes over up to 1.26 GB f32
 // activations per 16 384-sample batch (19 ms, 80 TFLOP/s, activation-traffic bound); here the
 // activations never leave the CU.  Convolutions are implicit GEMMs on the bf16 matrix cores
-// (v_mfma_f32_32x32x16_bf16, f32 accumulate):  D[cout][pixel] = W[cout][k] . X[k][pixel],
+// (v_mfma_f32_16x16x32_bf16, f32 accumulate):  D[cout][pixel] = W[cout][k] . X[k][pixel],
 // k = tap * Cin + c.  Activations live channels-last in a zero-haloed 12 x 17 LDS tile
-// ([position][channel], 272-B position stride so that the 16-B fragment reads of 32 consecutive pixels
-// spread over the banks); the B fragment of lane (pixel r, half h) for k-step (tap, 16-channel group)
+// ([position][channel], 272-B position stride so that the 16-B fragment reads of 16 consecutive pixels
+// spread over the banks); the B fragment of lane (pixel r, k-group g) for k-step (tap, 32-channel group)
 // is one ds_read_b128 at position(r) + tap offset.  Weights are pre-packed on the host so that the A
-// fragment of a lane is one coalesced 16-B global load (L2-resident: 486 KB bf16 for all four layers);
-// a wave owns one 32-channel row block and all 5 pixel tiles, so each weight fragment is loaded once per
-// sample and reused by 5 MFMAs.  The accumulator layout (column = pixel on the lane, rows = channels
-// in registers, 4 consecutive channels per register quad) makes the LayerNorm epilogue write 8-B packed
-// bf16 quads straight into the next layer's tile.  LayerNorm([C,H,W]) statistics are f32 sums over the
-// whole sample (one cross-wave reduction per layer); affine parameters are pre-transposed to
-// [pixel][channel].
+// fragment of a lane is one coalesced 16-B global load (L2-resident: 486 KB bf16 for all four layers).
+// The accumulator layout (column = pixel on the lane, 4 consecutive channels per register quad) makes the
+// LayerNorm epilogue write 8-B packed bf16 quads straight into the next layer's tile.  LayerNorm([C,H,W])
+// statistics are f32 sums over the whole sample (one cross-wave reduction per layer); affine parameters are
+// packed fp16 [pixel][channel/4][weight x4 | bias x4], one 16-B load per accumulator tile.
+//
+// The same file holds the training side: the SAVE variant of the forward, the backward
+// kernel (LayerNorm / ReLU backward + transposed implicit GEMMs), the weight-gradient kernel (MFMA over pixels
+// through ds_read_b64_tr_b16) and the parameter-gradient reduction kernel.
 //
 // Numerics: bf16 operands, f32 accumulation, f32 LayerNorm, bf16 activations between layers -- NOT
 // bit-comparable with the f32 reference policy; tests bound the difference (tests/test_gpu_policy.py).
