@@ -238,8 +238,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (bf16)fmaxf(fmaf((float)xq[e], (float)q[e], (float)q[4 + e]), 0.0f);
                     const size_t go = (size_t)pix[i] * COUT + ch0;
-                    *reinterpret_cast<bf16x4 *>(sv.xhat + go) = xq;
-                    if (sv.act) *reinterpret_cast<bf16x4 *>(sv.act + go) = o;
+                    *reinterpret_cast<bf16x4 *>(sv.xhat + go) = xq;       // (the activation leaves through the tile, below)
                 } else {
                 o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), (float)q[0], (float)q[4]), 0.0f);
                 o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), (float)q[1], (float)q[5]), 0.0f);
@@ -254,6 +253,15 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         __builtin_amdgcn_sched_barrier(0);                         // at most two groups' parameter sets live at a time
     }
     __syncthreads();
+    if (SAVE && sv.act) {
+        // the saved activation = the finished tile, written out as whole 2*COUT-byte rows (16 B per lane, coalesced):
+        // 8-B quads straight from the epilogue registers cost 0.26 ms more per 16 384 samples
+        bf16x8 *dst = reinterpret_cast<bf16x8 *>(sv.act);
+        for (int q = threadIdx.x; q < P * (COUT / 8); q += THREADS) {
+            const int p = q / (COUT / 8), part = q - p * (COUT / 8);
+            dst[q] = *reinterpret_cast<const bf16x8 *>(tile + pos_of(p) * CSTRIDE + part * 8);
+        }
+    }
     STAMP(9 + layer);                                                // epilogue + barrier
 }
 
@@ -498,7 +506,10 @@ __device__ __forceinline__ void ln_relu_bwd(const void *ln_packed, const bf16 *x
     __syncthreads();                                 // dz tile complete (B operand of the transposed convolution); red[] reusable
 }
 
-__global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_params prm, inv_policy_saved sv, const bf16 *__restrict__ dfeat,
+// One block per CU (launch bound 1): at two blocks per CU the 256-register budget makes hipcc spill 460 B/lane in this
+// kernel and it runs 4.3 ms per 16 384 samples; with the whole register file it is spill-free and takes 3.0 ms.
+// (The forward kernels are the opposite: 1.43 ms at two blocks per CU, 2.10 ms at one.)
+__global__ __launch_bounds__(THREADS, 1) void k_policy_trunk_bwd(inv_policy_bwd_params prm, inv_policy_saved sv, const bf16 *__restrict__ dfeat,
                                                               inv_policy_grads gr, int N)
 {
     __shared__ __attribute__((aligned(16))) bf16 tile[NPOS * CSTRIDE];
@@ -814,7 +825,8 @@ extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const i
     for (int l = 0; l < 4; ++l)
         if (!params->ln[l] || !grads->dy[l] || !grads->dz[l] || (l < 3 && !params->wt[l])) return INV_ERR_BAD_ARG;
     if (N == 0) return INV_OK;
-    hipLaunchKernelGGL(pol::k_policy_trunk_bwd, dim3(trunk_grid(N)), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, *saved,
+    const int cus = trunk_grid(1 << 30) / 2, grid = N < cus ? N : cus;   // one resident block per CU, persistent over samples
+    hipLaunchKernelGGL(pol::k_policy_trunk_bwd, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, *saved,
                        reinterpret_cast<const pol::bf16 *>(dfeat_bf16), *grads, (int)N);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }
