@@ -113,10 +113,12 @@ def test_update_with_bf16_autocast():
     assert np.isfinite(res["policy_loss"]) and np.isfinite(res["value_loss"]) and res["entropy"] > 2.0
 
 
-def test_two_rank_training_rehearsal():
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_rank_training_rehearsal(fused):
     """The multi-rank training path (env shards by global index, flat gradient all-reduce, global advantage
     statistics) with two processes sharing the one GPU of the test box over gloo: both ranks finish the same
-    number of steps and hold identical parameters."""
+    number of steps and hold identical parameters.  fused: rollouts and the update's trunk through the HIP policy kernels
+    (packed observations, gradients of the custom autograd Function accumulate into the flat all-reduce bucket)."""
     import socket
     import subprocess
     import sys
@@ -127,7 +129,8 @@ def test_two_rank_training_rehearsal():
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), INVERSUS_DIST_BACKEND="gloo", INVERSUS_SHARE_DEVICE="1", PYTHONPATH=root)
+                   MASTER_PORT=str(port), INVERSUS_DIST_BACKEND="gloo", INVERSUS_SHARE_DEVICE="1", PYTHONPATH=root,
+                   INVERSUS_TEST_FUSED="1" if fused else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "_dist_train_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
