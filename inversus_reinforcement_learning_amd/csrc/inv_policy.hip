@@ -119,10 +119,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
 
     const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
-#ifndef POL_AD
-#define POL_AD 3
-#endif
-    constexpr int AD = POL_AD;                                            // weight fragments are requested AD k-steps ahead (L2 latency)
+    constexpr int AD = 3;                                            // weight fragments are requested AD k-steps ahead (L2 latency; 2 and 4 measured equal)
     bf16x8 a[AD + 1][MW], b[NW];
 #pragma unroll
     for (int d = 0; d < AD; ++d)
@@ -174,26 +171,13 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             }
         }
     }
-    // LayerNorm parameters travel in groups of G tiles (one L2 round trip per group, 2 x G float4 registers per
-    // lane).  POL_LNPIPE: group g+1 is requested before group g is consumed, and group 0 before the statistics
-    // reduction, so a wave sees one exposed round trip per layer instead of one per group.
+    // LayerNorm parameters travel in groups of G tiles (one L2 round trip per group, G x 4 registers per lane).
+    // lp.ln: fp16 [pixel][COUT/4][8] = {weight x4, bias x4} of 4 consecutive channels: ONE 16-byte load per tile.
+    // (Requesting group g+1 before group g is consumed, or group 0 before the statistics reduction, was measured:
+    // the double buffer spills and is slower, the early request stopped mattering once the parameters were fp16.)
     constexpr int G = NW < 5 ? NW : 5, GPM = NW / G, NG = MW * GPM;
     static_assert(NW % G == 0, "tiles per wave must be a multiple of the parameter group");
-#ifdef POL_LNPIPE
-    f16x8 ln[2][G];
-#else
-    f16x8 ln[1][G];
-#endif
-    // lp.ln: fp16 [pixel][COUT/4][8] = {weight x4, bias x4} of 4 consecutive channels: ONE 16-byte load per tile
-    auto load_group = [&](int g, int buf) {
-        const int mi = g / GPM, i0 = (g - mi * GPM) * G, ch0 = (m0 + mi) * 16 + 4 * kg;
-#pragma unroll
-        for (int j = 0; j < G; ++j)
-            ln[buf][j] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(lp.ln) + ((size_t)min(pix[i0 + j], P - 1) * COUT + ch0) * 2);
-    };
-#if defined(POL_LNPIPE) || defined(POL_LNPRE)
-    load_group(0, 0);
-#endif
+    f16x8 ln[G];
     s = wave_sum(s);
     ss = wave_sum(ss);
     const int wave = threadIdx.x >> 6;
@@ -213,22 +197,15 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int mi = g / GPM, i0 = (g - mi * GPM) * G, ch0 = (m0 + mi) * 16 + 4 * kg;
-#ifdef POL_LNPIPE
-        const int buf = g & 1;
-        if (g + 1 < NG) load_group(g + 1, buf ^ 1);
-#elif defined(POL_LNPRE)
-        const int buf = 0;
-        if (g > 0) load_group(g, 0);
-#else
-        const int buf = 0;
-        load_group(g, 0);
-#endif
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            ln[j] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(lp.ln) + ((size_t)min(pix[i0 + j], P - 1) * COUT + ch0) * 2);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int i = i0 + j;
             if (i < ncount && pix[i] < P) {
                 bf16x4 o;
-                const f16x8 q = ln[buf][j];
+                const f16x8 q = ln[j];
                 if (SAVE) {
                     // the backward pass recomputes y = x^ * w + b from the ROUNDED x^ it reads back, so the forward
                     // activation is computed from the same rounded value (consistent ReLU mask)
@@ -250,7 +227,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
                 *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);                         // at most two groups' parameter sets live at a time
+        __builtin_amdgcn_sched_barrier(0);                         // one group's parameter set live at a time
     }
     __syncthreads();
     if (SAVE && sv.act) {
