@@ -12,7 +12,8 @@ GAE layout:
   * "per_env" (default) scans each env's own trajectory -- the reference's own num_envs == 1
     behaviour applied per env.  It is what multi-GPU sharding needs (no cross-env coupling).
 Deviations from the reference that cannot be bit-matched in parallel (global-RNG consumers):
-Categorical sampling and the minibatch permutation use torch's device generator.
+Categorical sampling and the minibatch permutation use torch's device generator (argument validation of the
+distribution object is off: it costs a device->host synchronisation per call, which stalls the launch queue).
 """
 import torch
 import torch.nn as nn
@@ -104,7 +105,7 @@ class PPOAgent:
                                         self._t(extra_vectors, torch.float32))
         else:
             logits, values = self.policy(self._planes(grid_tensors), self._t(extra_vectors, torch.float32))
-        dist = torch.distributions.Categorical(logits=logits)
+        dist = torch.distributions.Categorical(logits=logits, validate_args=False)
         actions = dist.sample()
         log_probs = dist.log_prob(actions)
         values = values.squeeze(-1)
@@ -170,7 +171,7 @@ class PPOAgent:
                                         enabled=self.update_autocast is not None):
                         logits, values = self.policy(self._planes(obs_grid[idx]), obs_extra[idx])
                 logits, values = logits.float(), values.float()
-                dist = torch.distributions.Categorical(logits=logits)
+                dist = torch.distributions.Categorical(logits=logits, validate_args=False)
                 new_log_probs = dist.log_prob(actions[idx])
                 entropy = dist.entropy().mean()
                 ratio = torch.exp(new_log_probs - old_log_probs[idx])

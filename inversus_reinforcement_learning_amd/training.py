@@ -71,7 +71,7 @@ class RolloutCollector:
         if self.packed and hasattr(self.opponent, "parameters"):      # an nn.Module opponent wants f32 planes
             grid = unpack_obs(grid, self.batch.H, self.batch.W)
         logits, _ = self.opponent(grid, self.obs_p2[1])
-        return torch.distributions.Categorical(logits=logits).sample().to(torch.uint8)
+        return torch.distributions.Categorical(logits=logits, validate_args=False).sample().to(torch.uint8)
 
     def collect(self, steps):
         b, agent = self.batch, self.agent

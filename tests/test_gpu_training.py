@@ -105,6 +105,21 @@ def test_training_loop_with_fused_actor(tmp_path):
     assert res["steps"] == 64 * 128 and np.isfinite(res["policy_loss"]) and np.isfinite(res["entropy"])
 
 
+def test_cli_fused_flag_trains_through_the_hip_policy_kernels(tmp_path):
+    """`--fused` on the CLI: fused actors, packed rollout buffer, fused update; writes the reference's file formats."""
+    import torch
+    from inversus_reinforcement_learning_amd import training
+    log = tmp_path / "cli"
+    res = training.main(["--mode", "vs_dummy", "--num_envs", "96", "--total_steps", str(96 * 128 * 2), "--log_dir", str(log),
+                         "--opponent_difficulty", "hard", "--seed", "5", "--fused", "--batch_size", "4096", "--epochs", "2"])
+    assert res["steps"] == 96 * 128 * 2 and np.isfinite(res["policy_loss"]) and np.isfinite(res["value_loss"])
+    assert 1.5 < res["entropy"] <= np.log(13) + 1e-3
+    sd = torch.load(log / "policy_final.pt", map_location="cpu", weights_only=True)
+    assert "conv1.weight" in sd and all(torch.isfinite(v).all() for v in sd.values())
+    with open(log / "training_log.csv") as f:
+        assert f.readline().strip() == "step,episode,avg_reward,win_rate,avg_ep_len,policy_loss,value_loss,entropy"
+
+
 def test_update_with_bf16_autocast():
     import torch
     from inversus_reinforcement_learning_amd import training

@@ -17,7 +17,7 @@ ft = FusedTrainPolicy(pol)
 def step(fwd):
     def f():
         lo, v = fwd()
-        d = torch.distributions.Categorical(logits=lo.float()); lp = d.log_prob(a); r = torch.exp(lp - olp)
+        d = torch.distributions.Categorical(logits=lo.float(), validate_args=False); lp = d.log_prob(a); r = torch.exp(lp - olp)
         loss = -torch.min(r * adv, torch.clamp(r, 0.8, 1.2) * adv).mean() + 0.1 * torch.nn.functional.mse_loss(v.float().squeeze(-1), ret) - 0.02 * d.entropy().mean()
         opt.zero_grad(); loss.backward(); torch.nn.utils.clip_grad_norm_(pol.parameters(), 0.5); opt.step()
     return f
