@@ -306,7 +306,7 @@ def main():
                          "kernel": "k_step", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would sit in the barrier)
             res["cpu_baseline"] = cpu_baseline(args.difficulty)
         if not args.no_extras and world == 1:
             del b, out, a1_all
