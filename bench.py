@@ -70,9 +70,30 @@ def cpu_baseline(difficulty, budget_s=12.0):
                 break
         return n * steps / dt, steps
 
+    def python_loop(n, budget):
+        """The reference's structure (env_wrappers.py:494-528): a Python loop over env OBJECTS, one C call per env for the
+        dummy, the step and the observation, np.stack at the end; single thread."""
+        envs = [orc.OracleEnv(W, H, seed=i) for i in range(n)]
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            obs = []
+            for i, e in enumerate(envs):
+                a1 = L.orc_uniform_action(1234, i, steps)
+                _, done, _ = e.step(a1, e.dummy_device(hard, 1, i))
+                if done:
+                    e.reset()
+                obs.append(e.build_observation(0))
+            np.stack([o[0] for o in obs]); np.stack([o[1] for o in obs])
+            steps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or steps >= 200000:
+                break
+        return n * steps / dt
+
     v, steps = run(NUM_ENVS, cores, budget_s)
     v1, _ = run(NUM_ENVS, 1, 3.0)
     v4, _ = run(4, 1, 1.0)
+    vpy = python_loop(4, 1.0)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -82,6 +103,7 @@ def cpu_baseline(difficulty, budget_s=12.0):
     return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} vector steps x {NUM_ENVS} envs, vs_dummy_{difficulty}, C oracle (OpenMP over envs), obs rendered",
             "one_core_env_steps_per_s": round(v1), "n4_one_core_env_steps_per_s": round(v4),
+            "n4_python_object_loop_env_steps_per_s": round(vpy),
             "host": {"cpu_model": model, "nproc": os.cpu_count()}}
 
 
