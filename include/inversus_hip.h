@@ -217,16 +217,16 @@ int  inv_policy_trunk_train_fwd(const inv_policy_params *params, const void *obs
                                 const inv_policy_saved *saved, int32_t N, void *stream);
 int  inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const inv_policy_saved *saved, const void *dfeat_bf16,
                           const inv_policy_grads *grads, int32_t N, void *stream);
-/* Weight gradient of convolution `layer` (0..3): dw[co][tap][ci] += sum_n sum_p dz[n][p][co] * x[n][p + tap][ci], f32
- * [Cout][9][CinP] (accumulated into: zero it first), tap = 3*ky + kx.  x: the layer's input, bf16 channels-last
- * [N][150][CinP] with CinP = 16, 32, 64, 128 (layer 0: the 12 observation planes padded with 4 zero channels);
- * dz: what inv_policy_trunk_bwd wrote.  MFMA over pixels through transposing LDS reads. */
-int  inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, int32_t N, void *stream);
-/* Batch reductions for the LayerNorm / bias gradients of one layer, one pass over dy, xhat, dz (bf16 [N][E], E = 150 * C):
- * partial[s][0][e] = sum dy*xhat, partial[s][1][e] = sum dy, partial[s][2][e] = sum dz over the samples n = s (mod slices);
- * f32 [slices][3][E], every entry written.  Adding the slices gives the LayerNorm weight / bias gradients in
- * [pixel][channel] order and (summed over pixels) the conv bias gradient. */
-int  inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, const void *dz_bf16, float *partial, int32_t slices,
+/* Weight (and bias) gradient of convolution `layer` (0..3): dw[co][tap][ci] += sum_n sum_p dz[n][p][co] * x[n][p + tap][ci],
+ * f32 [Cout][9][CinP], tap = 3*ky + kx; dbias[co] += sum_n sum_p dz[n][p][co] (f32 [Cout], may be NULL).  Both are
+ * accumulated into: zero them first.  x: the layer's input, bf16 channels-last [N][150][CinP] with CinP = 16, 32, 64, 128
+ * (layer 0: the 12 observation planes padded with 4 zero channels); dz: what inv_policy_trunk_bwd wrote.
+ * MFMA over pixels through transposing LDS reads. */
+int  inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, float *dbias, int32_t N, void *stream);
+/* Batch reductions for the LayerNorm gradients of one layer, one pass over dy and xhat (bf16 [N][E], E = 150 * C):
+ * partial[s][0][e] = sum dy*xhat, partial[s][1][e] = sum dy over the samples n = s (mod slices); f32 [slices][2][E], every
+ * entry written.  Adding the slices gives the LayerNorm weight / bias gradients in [pixel][channel] order. */
+int  inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, float *partial, int32_t slices,
                             int32_t elems_per_sample, int32_t N, void *stream);
 
 #ifdef __cplusplus

@@ -88,8 +88,8 @@ SIGNATURES = {
     "inv_policy_trunk_bits": (C.c_int, [P(InvPolicyParams), _V, _V, C.c_int32, _V]),
     "inv_policy_trunk_train_fwd": (C.c_int, [P(InvPolicyParams), _V, C.c_int32, _V, P(InvPolicySaved), C.c_int32, _V]),
     "inv_policy_trunk_bwd": (C.c_int, [P(InvPolicyBwdParams), P(InvPolicySaved), _V, P(InvPolicyGrads), C.c_int32, _V]),
-    "inv_policy_wgrad": (C.c_int, [C.c_int32, _V, _V, _V, C.c_int32, _V]),
-    "inv_policy_param_grads": (C.c_int, [_V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V]),
+    "inv_policy_wgrad": (C.c_int, [C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
+    "inv_policy_param_grads": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V]),
 }
 
 _lib = None

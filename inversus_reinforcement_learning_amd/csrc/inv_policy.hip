@@ -584,7 +584,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16 *row_lo, const bf16 *row_hi
 constexpr int WG_THREADS = 512, WG_WAVES = 8, KPAD = 160;
 
 template <int CINP, int COUT, int MWW, int NBW>
-__global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restrict__ x, const bf16 *__restrict__ dz, float *__restrict__ dw, int N)
+__global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restrict__ x, const bf16 *__restrict__ dz, float *__restrict__ dw, float *__restrict__ db, int N)
 {
     constexpr int MSLOTS = WG_WAVES / NBW, MS = MWW * MSLOTS;            // m-blocks (16 channels) per block
     constexpr int MBLOCKS = COUT / 16, Q = (MBLOCKS + MS - 1) / MS;       // output slices (blockIdx.x % Q)
@@ -628,14 +628,20 @@ __global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restr
     const int arow = (8 * g + q) * DSTRIDE + mb0 * 16 + p4;
 
     constexpr int DZ_CHUNKS = DCH / 8, X_CHUNKS = CINP / 8;              // 16-byte chunks per pixel row
+    static_assert(WG_THREADS % DZ_CHUNKS == 0, "a thread must always load the same channel chunk of dz");
+    float zsum[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };         // sum over this thread's pixels and samples of its 8 channels of dz
     const int dcols = min(DCH, COUT - co_base);                          // channels of the slice that exist
     for (int n = sidx; n < N; n += nslices) {
         __syncthreads();                                                 // previous sample's reads are done (and the zero fill)
         const bf16 *dzn = dz + (size_t)n * P * COUT + co_base;
         for (int c = tid; c < P * DZ_CHUNKS; c += WG_THREADS) {
             const int px = c / DZ_CHUNKS, part = c - px * DZ_CHUNKS;
-            if (part * 8 < dcols)
-                *reinterpret_cast<bf16x8 *>(dzt + px * DSTRIDE + part * 8) = *reinterpret_cast<const bf16x8 *>(dzn + (size_t)px * COUT + part * 8);
+            if (part * 8 < dcols) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(dzn + (size_t)px * COUT + part * 8);
+                *reinterpret_cast<bf16x8 *>(dzt + px * DSTRIDE + part * 8) = v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zsum[j] += (float)v[j];      // conv bias gradient on the way (this thread's 8 channels)
+            }
         }
         const bf16 *xn = x + (size_t)n * P * CINP;
         for (int c = tid; c < P * X_CHUNKS; c += WG_THREADS) {
@@ -661,6 +667,20 @@ __global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restr
             }
         }
     }
+    if (db) {                                                            // every dz element is loaded by exactly one block
+        // block-level sum in LDS first (the dz tile is free now): one global atomic per channel and block, not per thread
+        __syncthreads();
+        float *zred = reinterpret_cast<float *>(wg_lds);
+        if (tid < DCH) zred[tid] = 0.0f;
+        __syncthreads();
+        const int part = tid % DZ_CHUNKS;
+        if (part * 8 < dcols) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(zred + part * 8 + j, zsum[j]);
+        }
+        __syncthreads();
+        if (tid < dcols) atomicAdd(db + co_base + tid, zred[tid]);
+    }
     if (active) {
         const int r = lane & 15;
 #pragma unroll
@@ -677,41 +697,36 @@ __global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restr
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Batch reductions behind the LayerNorm / bias gradients: for every element e of a layer's [150][C] map
-//   g_w[e] = sum_n dy[n][e] * xhat[n][e]      g_b[e] = sum_n dy[n][e]      g_z[e] = sum_n dz[n][e]
-// (conv bias gradient = g_z summed over the 150 pixels by the caller).  One pass over the three bf16 tensors: a thread
-// owns 8 consecutive channels (16-byte loads), blockIdx.y strides over the samples and writes its partial sums to
-// part[slice][3][E]; the caller adds the slices.
-__global__ __launch_bounds__(256) void k_policy_param_grads(const bf16 *__restrict__ dy, const bf16 *__restrict__ xhat, const bf16 *__restrict__ dz,
+// Batch reductions behind the LayerNorm gradients: for every element e of a layer's [150][C] map
+//   g_w[e] = sum_n dy[n][e] * xhat[n][e]      g_b[e] = sum_n dy[n][e]
+// One pass over the two bf16 tensors: a thread owns 8 consecutive channels (16-byte loads), blockIdx.y strides over the
+// samples and writes its partial sums to part[slice][2][E]; the caller adds the slices.  (The conv bias gradient, the
+// sum of dz, is collected by k_policy_wgrad while it stages dz.)
+__global__ __launch_bounds__(256) void k_policy_param_grads(const bf16 *__restrict__ dy, const bf16 *__restrict__ xhat,
                                                         float *__restrict__ part, int E8, int N)
 {
     const int e8 = blockIdx.x * 256 + threadIdx.x;
     if (e8 >= E8) return;
-    float aw[8], ab[8], az[8];
+    float aw[8], ab[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) aw[j] = ab[j] = az[j] = 0.0f;
+    for (int j = 0; j < 8; ++j) aw[j] = ab[j] = 0.0f;
     const size_t stride = (size_t)E8 * 8;
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
         const size_t o = (size_t)n * stride + (size_t)e8 * 8;
         const bf16x8 d = *reinterpret_cast<const bf16x8 *>(dy + o);
         const bf16x8 x = *reinterpret_cast<const bf16x8 *>(xhat + o);
-        const bf16x8 z = *reinterpret_cast<const bf16x8 *>(dz + o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float df = (float)d[j];
             aw[j] = fmaf(df, (float)x[j], aw[j]);
             ab[j] += df;
-            az[j] += (float)z[j];
         }
     }
-    // partial sums of this sample slice, [slice][3][E]: no atomics (they would all land on the same 3 E addresses)
-    float *o = part + (size_t)blockIdx.y * 3 * stride + (size_t)e8 * 8;
+    float *o = part + (size_t)blockIdx.y * 2 * stride + (size_t)e8 * 8;
     *reinterpret_cast<float4 *>(o) = make_float4(aw[0], aw[1], aw[2], aw[3]);
     *reinterpret_cast<float4 *>(o + 4) = make_float4(aw[4], aw[5], aw[6], aw[7]);
     *reinterpret_cast<float4 *>(o + stride) = make_float4(ab[0], ab[1], ab[2], ab[3]);
     *reinterpret_cast<float4 *>(o + stride + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
-    *reinterpret_cast<float4 *>(o + 2 * stride) = make_float4(az[0], az[1], az[2], az[3]);
-    *reinterpret_cast<float4 *>(o + 2 * stride + 4) = make_float4(az[4], az[5], az[6], az[7]);
 }
 
 }  // namespace pol
@@ -809,7 +824,7 @@ extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const i
 }
 
 template <int CINP, int COUT, int MWW, int NBW>
-static int launch_wgrad(const void *x, const void *dz, float *dw, int N, hipStream_t st)
+static int launch_wgrad(const void *x, const void *dz, float *dw, float *db, int N, hipStream_t st)
 {
     constexpr int MS = MWW * (pol::WG_WAVES / NBW), Q = (COUT / 16 + MS - 1) / MS;
     constexpr int DSTRIDE = MS * 16 + 8, XSTRIDE = CINP + 8;
@@ -823,29 +838,29 @@ static int launch_wgrad(const void *x, const void *dz, float *dw, int N, hipStre
     const int per_slice = trunk_grid(N) / Q > 0 ? trunk_grid(N) / Q : 1;             // two 8-wave blocks per CU (<= 126 VGPRs, <= 68 KB LDS)
     const int nslices = N < per_slice ? N : per_slice;
     hipLaunchKernelGGL((pol::k_policy_wgrad<CINP, COUT, MWW, NBW>), dim3(nslices * Q), dim3(pol::WG_THREADS), lds, st,
-                       reinterpret_cast<const pol::bf16 *>(x), reinterpret_cast<const pol::bf16 *>(dz), dw, N);
+                       reinterpret_cast<const pol::bf16 *>(x), reinterpret_cast<const pol::bf16 *>(dz), dw, db, N);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }
 
-extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, int32_t N, void *stream)
+extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, float *dbias, int32_t N, void *stream)
 {
     if (!x_bf16 || !dz_bf16 || !dw || N < 0 || layer < 0 || layer > 3) return INV_ERR_BAD_ARG;
     if (N == 0) return INV_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (layer) {
-    case 0: return launch_wgrad<16, 32, 1, 1>(x_bf16, dz_bf16, dw, N, st);
-    case 1: return launch_wgrad<32, 64, 1, 2>(x_bf16, dz_bf16, dw, N, st);
-    case 2: return launch_wgrad<64, 128, 2, 4>(x_bf16, dz_bf16, dw, N, st);
-    default: return launch_wgrad<128, 128, 2, 8>(x_bf16, dz_bf16, dw, N, st);
+    case 0: return launch_wgrad<16, 32, 1, 1>(x_bf16, dz_bf16, dw, dbias, N, st);
+    case 1: return launch_wgrad<32, 64, 1, 2>(x_bf16, dz_bf16, dw, dbias, N, st);
+    case 2: return launch_wgrad<64, 128, 2, 4>(x_bf16, dz_bf16, dw, dbias, N, st);
+    default: return launch_wgrad<128, 128, 2, 8>(x_bf16, dz_bf16, dw, dbias, N, st);
     }
 }
 
-extern "C" int inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, const void *dz_bf16, float *partial, int32_t slices,
+extern "C" int inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, float *partial, int32_t slices,
                                       int32_t elems_per_sample, int32_t N, void *stream)
 {
-    if (!dy_bf16 || !xhat_bf16 || !dz_bf16 || !partial || N < 0 || slices < 1 || elems_per_sample <= 0 || (elems_per_sample & 7)) return INV_ERR_BAD_ARG;
+    if (!dy_bf16 || !xhat_bf16 || !partial || N < 0 || slices < 1 || elems_per_sample <= 0 || (elems_per_sample & 7)) return INV_ERR_BAD_ARG;
     const int e8 = elems_per_sample / 8, bx = (e8 + 255) / 256;
     hipLaunchKernelGGL(pol::k_policy_param_grads, dim3(bx, slices), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const pol::bf16 *>(dy_bf16),
-                       reinterpret_cast<const pol::bf16 *>(xhat_bf16), reinterpret_cast<const pol::bf16 *>(dz_bf16), partial, e8, (int)N);
+                       reinterpret_cast<const pol::bf16 *>(xhat_bf16), partial, e8, (int)N);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }

@@ -8,7 +8,7 @@ with respect to the module's parameters, but the convolutional trunk (policies.p
                                                             gradient of the convolutions (transposed implicit GEMMs)
 
 and the parameter gradients are batch reductions over the tensors that kernel writes (dy, dz; channels-last bf16):
-LayerNorm weight / bias and conv bias by one reduction kernel per layer (k_policy_param_grads), conv weights by
+LayerNorm weight / bias by one reduction kernel per layer (k_policy_param_grads), conv weights and biases by
 k_policy_wgrad (MFMA over pixels through transposing LDS reads).
 The two MLP heads stay in torch autograd; their 19 200-column first layer runs in bf16 on the kernel's feature order.
 
@@ -59,18 +59,19 @@ def _wgrad_torch(x, dz, cin, cout):
 
 
 def _wgrad(layer, x, dz):
-    """Weight gradient of conv `layer` through inv_policy_wgrad (MFMA over pixels, transposing LDS reads).
-    x: bf16 [N,150,CinP] contiguous layer input, dz: bf16 [N,150,Cout] -> f32 [Cout, Cin, 3, 3]."""
+    """Weight and bias gradient of conv `layer` through inv_policy_wgrad (MFMA over pixels, transposing LDS reads).
+    x: bf16 [N,150,CinP] contiguous layer input, dz: bf16 [N,150,Cout] -> (f32 [Cout, Cin, 3, 3], f32 [Cout])."""
     lib = L.load()
     cin, cinp, cout = _CIN[layer], _CINP[layer], _COUT[layer]
     assert x.dtype == dz.dtype == torch.bfloat16 and x.is_contiguous() and dz.is_contiguous()
     assert tuple(x.shape[1:]) == (150, cinp) and tuple(dz.shape[1:]) == (150, cout)
     dw = torch.zeros((cout, 9, cinp), dtype=torch.float32, device=x.device)
+    db = torch.zeros((cout,), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.inv_policy_wgrad(layer, _ptr(x), _ptr(dz), _ptr(dw), x.shape[0],
+        rc = lib.inv_policy_wgrad(layer, _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), x.shape[0],
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
     L.raise_for(rc, lib)
-    return dw[:, :, :cin].reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+    return dw[:, :, :cin].reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous(), db
 
 
 class _TrunkTrainFn(torch.autograd.Function):
@@ -148,15 +149,15 @@ class _TrunkTrainFn(torch.autograd.Function):
         for i in range(4):
             c = _COUT[i]
             x_in = x0 if i == 0 else act[i - 1]
-            dw = _wgrad(i, x_in, dz[i])
+            dw, db = _wgrad(i, x_in, dz[i])
             slices = max(1, min(n, _RED_SLICES))
-            part = torch.empty((slices, 3, 150, c), dtype=torch.float32, device=dev)       # per-slice sums of dy*x^, dy, dz
+            part = torch.empty((slices, 2, 150, c), dtype=torch.float32, device=dev)       # per-slice sums of dy*x^, dy
             with torch.cuda.device(dev):
-                rc = lib.inv_policy_param_grads(_ptr(dy[i]), _ptr(xhat[i]), _ptr(dz[i]), _ptr(part), slices, 150 * c, n,
+                rc = lib.inv_policy_param_grads(_ptr(dy[i]), _ptr(xhat[i]), _ptr(part), slices, 150 * c, n,
                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
             L.raise_for(rc, lib)
             red = part.sum(dim=0)
-            dg, de, db = red[0].t().reshape(c, 10, 15), red[1].t().reshape(c, 10, 15), red[2].sum(dim=0)
+            dg, de = red[0].t().reshape(c, 10, 15), red[1].t().reshape(c, 10, 15)
             out += [dw, db, dg, de]
         return tuple(out)
 

@@ -43,5 +43,5 @@ res["x0 build (12 planes -> [B,150,16] bf16)"] = t(lambda: torch.zeros((B, 150, 
 for i in range(4):
     x_in = x0 if i == 0 else act[i - 1]
     res[f"wgrad L{i+1} (HIP kernel)"] = t(lambda: FT._wgrad(i, x_in, dz[i]), 3, 1)
-    res[f"ln/bias reductions L{i+1}"] = t(lambda: (dz[i].sum(dim=(0, 1), dtype=torch.float32), (dy[i] * xhat[i]).sum(dim=0, dtype=torch.float32), dy[i].sum(dim=0, dtype=torch.float32)), 3, 1)
+    res[f"ln/bias reductions L{i+1}"] = t(lambda: ((dy[i] * xhat[i]).sum(dim=0, dtype=torch.float32), dy[i].sum(dim=0, dtype=torch.float32)), 3, 1)
 print(json.dumps(res, indent=1))
