@@ -194,6 +194,44 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     const float shift = -mean * rstd;
     if (SAVE && threadIdx.x == 0) *sv.rstd = rstd;
 
+    if constexpr (SAVE) {
+        // Training forward: x^ (rounded to bf16) goes into the tile in place of the activation, then ONE row pass by all
+        // threads writes x^ to HBM as whole 2*COUT-byte rows, applies the affine + ReLU to what it just read (so the
+        // backward, which recomputes y = x^ * w + b from the stored x^, sees the same ReLU mask) and leaves the activation
+        // in the tile and in HBM -- coalesced 16-B stores instead of 8-B quads scattered from the accumulator layout.
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) {
+            const int ch0 = (m0 + mi) * 16 + 4 * kg;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                if (i < ncount && pix[i] < P) {
+                    bf16x4 xq;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xq[e] = (bf16)fmaf(acc[mi][i][e], rstd, shift);
+                    *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = xq;
+                }
+            }
+        }
+        __syncthreads();
+        bf16x8 *xdst = reinterpret_cast<bf16x8 *>(sv.xhat), *adst = reinterpret_cast<bf16x8 *>(sv.act);
+        for (int q = threadIdx.x; q < P * (COUT / 8); q += THREADS) {
+            const int p = q / (COUT / 8), part = q - p * (COUT / 8);
+            bf16 *tp = tile + pos_of(p) * CSTRIDE + part * 8;
+            const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(tp);
+            xdst[q] = xv;
+            const _Float16 *lq = reinterpret_cast<const _Float16 *>(lp.ln) + ((size_t)p * COUT + part * 8) * 2;
+            const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (bf16)fmaxf(fmaf((float)xv[e], (float)l0[e], (float)l0[4 + e]), 0.0f);
+                o[4 + e] = (bf16)fmaxf(fmaf((float)xv[4 + e], (float)l1[e], (float)l1[4 + e]), 0.0f);
+            }
+            *reinterpret_cast<bf16x8 *>(tp) = o;
+            if (adst) adst[q] = o;
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int mi = g / GPM, i0 = (g - mi * GPM) * G, ch0 = (m0 + mi) * 16 + 4 * kg;
@@ -206,22 +244,10 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             if (i < ncount && pix[i] < P) {
                 bf16x4 o;
                 const f16x8 q = ln[j];
-                if (SAVE) {
-                    // the backward pass recomputes y = x^ * w + b from the ROUNDED x^ it reads back, so the forward
-                    // activation is computed from the same rounded value (consistent ReLU mask)
-                    bf16x4 xq;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) xq[e] = (bf16)fmaf(acc[mi][i][e], rstd, shift);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)fmaxf(fmaf((float)xq[e], (float)q[e], (float)q[4 + e]), 0.0f);
-                    const size_t go = (size_t)pix[i] * COUT + ch0;
-                    *reinterpret_cast<bf16x4 *>(sv.xhat + go) = xq;       // (the activation leaves through the tile, below)
-                } else {
                 o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), (float)q[0], (float)q[4]), 0.0f);
                 o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), (float)q[1], (float)q[5]), 0.0f);
                 o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), (float)q[2], (float)q[6]), 0.0f);
                 o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), (float)q[3], (float)q[7]), 0.0f);
-                }
                 // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
                 // above, and the residual read of this lane's own elements precedes this write
                 *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
@@ -230,14 +256,6 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         __builtin_amdgcn_sched_barrier(0);                         // one group's parameter set live at a time
     }
     __syncthreads();
-    if (SAVE && sv.act) {
-        // the saved activation = the finished tile, written out as whole 2*COUT-byte rows (16 B per lane, coalesced):
-        // 8-B quads straight from the epilogue registers cost 0.26 ms more per 16 384 samples
-        bf16x8 *dst = reinterpret_cast<bf16x8 *>(sv.act);
-        for (int q = threadIdx.x; q < P * (COUT / 8); q += THREADS) {
-            const int p = q / (COUT / 8), part = q - p * (COUT / 8);
-            dst[q] = *reinterpret_cast<const bf16x8 *>(tile + pos_of(p) * CSTRIDE + part * 8);
-        }
     }
     STAMP(9 + layer);                                                // epilogue + barrier
 }
