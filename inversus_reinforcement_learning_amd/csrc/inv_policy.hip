@@ -384,8 +384,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
 //   dz  = rstd * (dx^ - mean(dx^) - x^ * mean(dx^ x^))         LayerNorm over the whole sample
 //   da' = convT(dz)  (+ dz for the residual of layer 4)         implicit GEMM with the transposed weights
 // dy and dz go to HBM (the parameter gradients are batch reductions / GEMMs over them), dz also into the LDS tile
-// as the B operand of the transposed convolution; da' stays in the accumulator registers, whose ownership is chosen
-// to equal the forward epilogue ownership of the layer below, so the next layer's LayerNorm backward runs on it in place.
+// as the B operand of the transposed convolution, whose result da' returns to the tile as bf16 for the next layer.
 
 // GEMM core of conv_ln_relu (same fragment layouts, same software pipeline), accumulators handed back to the caller.
 template <int CIN, int COUT, int MW, int NW>
@@ -432,80 +431,107 @@ __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int l
     }
 }
 
-// LayerNorm + ReLU backward of one layer on the accumulator registers (in: da, ownership MW x NW tiles from m0 / n0).
-template <int COUT, int MW, int NW>
-__device__ __forceinline__ void ln_relu_bwd(const void *ln_packed, const bf16 *xhat_n, float rstd, bf16 *dy_n, bf16 *dz_n,
-                                            bf16 *tile, float *red, int lane, int m0, int n0, f32x4 (&acc)[MW][NW])
+// The LayerNorm / ReLU backward does not need the accumulator layout: da goes through the LDS tile as bf16 and ALL 256
+// threads walk the sample row by row (8 channels = 16 B per item), so every HBM access is a coalesced 16-byte piece of a
+// whole row, the work is balanced over the block, and almost nothing is live across the reductions -- the kernel fits two
+// blocks per CU without spilling, like the forward (2.4 ms per 16 384 samples; a first version that ran the LayerNorm
+// backward on the GEMM's accumulator registers spilled 460 B/lane at two blocks per CU (4.3 ms) and needed one block per
+// CU with the whole register file to reach 3.0 ms).  Per layer: [A] dy = da * mask, sums of dx^ and dx^ x^ -> [B] dz into
+// the tile and HBM -> transposed implicit GEMM on the tile -> da' (bf16) back into the tile.
+
+// pass A + B of one layer.  FROM_GLOBAL: da comes from HBM (layer 4: dfeat) instead of the tile.
+template <int COUT, bool FROM_GLOBAL>
+__device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf16 *xhat_n, float rstd, const bf16 *da_n, bf16 *dy_n, bf16 *dz_n,
+                                                 bf16 *tile, float *red)
 {
-    const int c16 = lane & 15, kg = lane >> 4;
-    int pix[NW], base[NW];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        pix[i] = (n0 + i) * 16 + c16;
-        base[i] = pos_of(min(pix[i], P - 1)) * CSTRIDE;
-    }
-    bf16x4 xh[MW][NW];
+    constexpr int CH8 = COUT / 8, ITEMS = P * CH8;
+    const int tid = threadIdx.x;
     float s1 = 0.0f, s2 = 0.0f;
+    for (int q = tid; q < ITEMS; q += THREADS) {
+        const int p = q / CH8, part = q - p * CH8;
+        bf16 *tp = tile + pos_of(p) * CSTRIDE + part * 8;
+        const bf16x8 da = FROM_GLOBAL ? reinterpret_cast<const bf16x8 *>(da_n)[q] : *reinterpret_cast<const bf16x8 *>(tp);
+        const bf16x8 xh = reinterpret_cast<const bf16x8 *>(xhat_n)[q];
+        const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;       // (p * COUT + part * 8) * 2
+        const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
+        bf16x8 dy;
 #pragma unroll
-    for (int mi = 0; mi < MW; ++mi) {
-        const int ch0 = (m0 + mi) * 16 + 4 * kg;
-        f16x8 ln[NW];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const size_t go = (size_t)min(pix[i], P - 1) * COUT + ch0;
-            ln[i] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(ln_packed) + go * 2);
-            xh[mi][i] = *reinterpret_cast<const bf16x4 *>(xhat_n + go);
+        for (int e = 0; e < 8; ++e) {
+            const float x = (float)xh[e], g = (float)(e < 4 ? l0[e] : l1[e - 4]), b = (float)(e < 4 ? l0[4 + e] : l1[e]);
+            const float d = fmaf(x, g, b) > 0.0f ? (float)da[e] : 0.0f;
+            dy[e] = (bf16)d;
+            const float dxh = (float)dy[e] * g;          // from the ROUNDED dy: pass B recomputes exactly this value
+            s1 += dxh;
+            s2 += dxh * x;
         }
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const bool valid = pix[i] < P;
-            bf16x4 dyq;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = (float)xh[mi][i][e], g = (float)ln[i][e];
-                const float y = fmaf(x, g, (float)ln[i][4 + e]);
-                const float d = (valid && y > 0.0f) ? acc[mi][i][e] : 0.0f;
-                const float dxh = d * g;
-                dyq[e] = (bf16)d;
-                acc[mi][i][e] = dxh;
-                s1 += dxh;
-                s2 += dxh * x;
-            }
-            if (valid) *reinterpret_cast<bf16x4 *>(dy_n + (size_t)pix[i] * COUT + ch0) = dyq;
-        }
+        reinterpret_cast<bf16x8 *>(dy_n)[q] = dy;
+        *reinterpret_cast<bf16x8 *>(tp) = dy;
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    const int wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     if (lane == 0) { red[wave] = s1; red[WAVES + wave] = s2; }
-    __syncthreads();                                 // also: every wave is past its reads of the tile (previous GEMM)
+    __syncthreads();
     float S1 = 0.0f, S2 = 0.0f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) { S1 += red[w]; S2 += red[WAVES + w]; }
     const float inv_cnt = 1.0f / (float)(COUT * P);
     const float m1 = S1 * inv_cnt, m2 = S2 * inv_cnt;
+    for (int q = tid; q < ITEMS; q += THREADS) {         // same items as in pass A: this thread's own tile entries
+        const int p = q / CH8, part = q - p * CH8;
+        bf16 *tp = tile + pos_of(p) * CSTRIDE + part * 8;
+        const bf16x8 dy = *reinterpret_cast<const bf16x8 *>(tp);
+        const bf16x8 xh = reinterpret_cast<const bf16x8 *>(xhat_n)[q];
+        const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;
+        const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
+        bf16x8 dz;
 #pragma unroll
-    for (int mi = 0; mi < MW; ++mi) {
-        const int ch0 = (m0 + mi) * 16 + 4 * kg;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            if (pix[i] < P) {
-                bf16x4 dzq;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dzq[e] = (bf16)(rstd * (acc[mi][i][e] - m1 - (float)xh[mi][i][e] * m2));
-                *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = dzq;
-                *reinterpret_cast<bf16x4 *>(dz_n + (size_t)pix[i] * COUT + ch0) = dzq;
-            }
+        for (int e = 0; e < 8; ++e) {
+            const float g = (float)(e < 4 ? l0[e] : l1[e - 4]);
+            dz[e] = (bf16)(rstd * ((float)dy[e] * g - m1 - (float)xh[e] * m2));
         }
+        reinterpret_cast<bf16x8 *>(dz_n)[q] = dz;
+        *reinterpret_cast<bf16x8 *>(tp) = dz;
     }
     __syncthreads();                                 // dz tile complete (B operand of the transposed convolution); red[] reusable
 }
 
-// One block per CU (launch bound 1): at two blocks per CU the 256-register budget makes hipcc spill 460 B/lane in this
-// kernel and it runs 4.3 ms per 16 384 samples; with the whole register file it is spill-free and takes 3.0 ms.
-// (The forward kernels are the opposite: 1.43 ms at two blocks per CU, 2.10 ms at one.)
-__global__ __launch_bounds__(THREADS, 1) void k_policy_trunk_bwd(inv_policy_bwd_params prm, inv_policy_saved sv, const bf16 *__restrict__ dfeat,
-                                                              inv_policy_grads gr, int N)
+// transposed conv of the dz tile -> da of the layer below, written back into the tile as bf16 (channels 0 .. COUT_BELOW)
+template <int CIN_T, int COUT_BELOW, int MW, int NW, bool RESIDUAL>
+__device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int lane, int m0, int n0)
+{
+    f32x4 acc[MW][NW];
+    conv_gemm<CIN_T, COUT_BELOW, MW, NW>(wt, tile, lane, m0, n0, acc);
+    const int c16 = lane & 15, kg = lane >> 4;
+    if (RESIDUAL) {                                  // z4 = conv4(a3) + b4 + a3: da3 += dz4 (this lane's own entries of the tile)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int px = min((n0 + i) * 16 + c16, P - 1);
+                const bf16x4 r = *reinterpret_cast<const bf16x4 *>(tile + pos_of(px) * CSTRIDE + (m0 + mi) * 16 + 4 * kg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mi][i][e] += (float)r[e];
+            }
+    }
+    __syncthreads();                                 // every wave has finished reading the dz tile
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int px = (n0 + i) * 16 + c16;
+            if (px < P) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[mi][i][e];
+                *reinterpret_cast<bf16x4 *>(tile + pos_of(px) * CSTRIDE + (m0 + mi) * 16 + 4 * kg) = o;
+            }
+        }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_params prm, inv_policy_saved sv, const bf16 *__restrict__ dfeat,
+                                                                   inv_policy_grads gr, int N)
 {
     __shared__ __attribute__((aligned(16))) bf16 tile[NPOS * CSTRIDE];
     __shared__ float red[2 * WAVES];
@@ -520,59 +546,20 @@ __global__ __launch_bounds__(THREADS, 1) void k_policy_trunk_bwd(inv_policy_bwd_
     __syncthreads();
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         int lane_i = lane;
-        asm volatile("" : "+v"(lane_i));             // keep per-lane addresses per-sample recomputations (see k_policy_trunk)
+        asm volatile("" : "+v"(lane_i));
         const size_t sn = (size_t)n * P;
         const float4 rs = *reinterpret_cast<const float4 *>(sv.rstd + (size_t)n * 4);
-        const int c16 = lane_i & 15, kg = lane_i >> 4;
-        // ---- layer 4 (128 ch, 4 x 5 ownership): da = dfeat
-        {
-            f32x4 acc[4][5];
-            const int m0 = (wave & 1) * 4, n0 = (wave >> 1) * 5;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int px = min((n0 + i) * 16 + c16, P - 1);
-                    const bf16x4 v = *reinterpret_cast<const bf16x4 *>(dfeat + (sn + px) * 128 + (m0 + mi) * 16 + 4 * kg);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[mi][i][e] = (float)v[e];
-                }
-            ln_relu_bwd<128, 4, 5>(prm.ln[3], reinterpret_cast<const bf16 *>(sv.xhat[3]) + sn * 128, rs.w,
-                                   reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128,
-                                   tile, red, lane_i, m0, n0, acc);
-            // da3 = convT4(dz4) + dz4 (residual: z4 = conv4(a3) + b4 + a3), same 4 x 5 ownership as layer 3's epilogue
-            f32x4 nxt[4][5];
-            conv_gemm<128, 128, 4, 5>(prm.wt[2], tile, lane_i, m0, n0, nxt);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int px = min((n0 + i) * 16 + c16, P - 1);
-                    const bf16x4 r = *reinterpret_cast<const bf16x4 *>(tile + pos_of(px) * CSTRIDE + (m0 + mi) * 16 + 4 * kg);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) nxt[mi][i][e] += (float)r[e];
-                }
-            // ---- layer 3 (128 ch)
-            ln_relu_bwd<128, 4, 5>(prm.ln[2], reinterpret_cast<const bf16 *>(sv.xhat[2]) + sn * 128, rs.z,
-                                   reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128,
-                                   tile, red, lane_i, m0, n0, nxt);
-        }
-        // ---- layer 2 (64 ch, 1 x 10 ownership): da2 = convT3(dz3)
-        {
-            f32x4 acc[1][10];
-            conv_gemm<128, 64, 1, 10>(prm.wt[1], tile, lane_i, wave, 0, acc);
-            ln_relu_bwd<64, 1, 10>(prm.ln[1], reinterpret_cast<const bf16 *>(sv.xhat[1]) + sn * 64, rs.y,
-                                   reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64, reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64,
-                                   tile, red, lane_i, wave, 0, acc);
-        }
-        // ---- layer 1 (32 ch, 1 x 5 ownership): da1 = convT2(dz2); no data gradient below (the observation)
-        {
-            f32x4 acc[1][5];
-            conv_gemm<64, 32, 1, 5>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5, acc);
-            ln_relu_bwd<32, 1, 5>(prm.ln[0], reinterpret_cast<const bf16 *>(sv.xhat[0]) + sn * 32, rs.x,
-                                  reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32, reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32,
-                                  tile, red, lane_i, wave & 1, (wave >> 1) * 5, acc);
-        }
+        ln_relu_bwd_rows<128, true>(prm.ln[3], reinterpret_cast<const bf16 *>(sv.xhat[3]) + sn * 128, rs.w, dfeat + sn * 128,
+                                    reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red);
+        conv_t_to_tile<128, 128, 4, 5, true>(prm.wt[2], tile, lane_i, (wave & 1) * 4, (wave >> 1) * 5);
+        ln_relu_bwd_rows<128, false>(prm.ln[2], reinterpret_cast<const bf16 *>(sv.xhat[2]) + sn * 128, rs.z, nullptr,
+                                     reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128, tile, red);
+        conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0);
+        ln_relu_bwd_rows<64, false>(prm.ln[1], reinterpret_cast<const bf16 *>(sv.xhat[1]) + sn * 64, rs.y, nullptr,
+                                    reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64, reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64, tile, red);
+        conv_t_to_tile<64, 32, 1, 5, false>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5);
+        ln_relu_bwd_rows<32, false>(prm.ln[0], reinterpret_cast<const bf16 *>(sv.xhat[0]) + sn * 32, rs.x, nullptr,
+                                    reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32, reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32, tile, red);
     }
 }
 
@@ -835,8 +822,7 @@ extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const i
     for (int l = 0; l < 4; ++l)
         if (!params->ln[l] || !grads->dy[l] || !grads->dz[l] || (l < 3 && !params->wt[l])) return INV_ERR_BAD_ARG;
     if (N == 0) return INV_OK;
-    const int cus = trunk_grid(1 << 30) / 2, grid = N < cus ? N : cus;   // one resident block per CU, persistent over samples
-    hipLaunchKernelGGL(pol::k_policy_trunk_bwd, dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, *saved,
+    hipLaunchKernelGGL(pol::k_policy_trunk_bwd, dim3(trunk_grid(N)), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, *saved,
                        reinterpret_cast<const pol::bf16 *>(dfeat_bf16), *grads, (int)N);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }
