@@ -588,8 +588,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16 *row_lo, const bf16 *row_hi
 
 constexpr int WG_THREADS = 512, WG_WAVES = 8, KPAD = 160;
 
-template <int CINP, int COUT, int MWW, int NBW>
-__global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restrict__ x, const bf16 *__restrict__ dz, float *__restrict__ dw, float *__restrict__ db, int N)
+// PF (the wide layers): one block per CU with twice the tiles per wave (MWW = 4: fewer output slices, so x / dz are
+// re-read less often, and fewer LDS reads per MFMA), and the NEXT sample's dz / x chunks are requested into registers
+// before the MFMAs of the current one, so the HBM / L2 latency of the tile fill overlaps the matrix work.
+template <int CINP, int COUT, int MWW, int NBW, bool PF>
+__global__ __launch_bounds__(WG_THREADS, PF ? 1 : 2) void k_policy_wgrad(const bf16 *__restrict__ x, const bf16 *__restrict__ dz, float *__restrict__ dw, float *__restrict__ db, int N)
 {
     constexpr int MSLOTS = WG_WAVES / NBW, MS = MWW * MSLOTS;            // m-blocks (16 channels) per block
     constexpr int MBLOCKS = COUT / 16, Q = (MBLOCKS + MS - 1) / MS;       // output slices (blockIdx.x % Q)
@@ -634,26 +637,42 @@ __global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restr
 
     constexpr int DZ_CHUNKS = DCH / 8, X_CHUNKS = CINP / 8;              // 16-byte chunks per pixel row
     static_assert(WG_THREADS % DZ_CHUNKS == 0, "a thread must always load the same channel chunk of dz");
+    constexpr int DZC = (P * DZ_CHUNKS + WG_THREADS - 1) / WG_THREADS, XC = (P * X_CHUNKS + WG_THREADS - 1) / WG_THREADS;
     float zsum[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };         // sum over this thread's pixels and samples of its 8 channels of dz
     const int dcols = min(DCH, COUT - co_base);                          // channels of the slice that exist
-    for (int n = sidx; n < N; n += nslices) {
-        __syncthreads();                                                 // previous sample's reads are done (and the zero fill)
-        const bf16 *dzn = dz + (size_t)n * P * COUT + co_base;
-        for (int c = tid; c < P * DZ_CHUNKS; c += WG_THREADS) {
-            const int px = c / DZ_CHUNKS, part = c - px * DZ_CHUNKS;
-            if (part * 8 < dcols) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(dzn + (size_t)px * COUT + part * 8);
-                *reinterpret_cast<bf16x8 *>(dzt + px * DSTRIDE + part * 8) = v;
+    const bool dz_mine = (tid % DZ_CHUNKS) * 8 < dcols;                  // this thread's channel chunk exists in the slice
+    bf16x8 rdz[DZC], rx[XC];                                             // one sample's chunks of this thread (PF: the next sample's)
+
+    auto fetch = [&](int n) {                                            // HBM / L2 -> registers
+        const bf16 *dzn = dz + (size_t)n * P * COUT + co_base, *xn = x + (size_t)n * P * CINP;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) zsum[j] += (float)v[j];      // conv bias gradient on the way (this thread's 8 channels)
+        for (int k = 0; k < DZC; ++k) {
+            const int c = tid + k * WG_THREADS, px = c / DZ_CHUNKS, part = c - px * DZ_CHUNKS;
+            if (c < P * DZ_CHUNKS && dz_mine) rdz[k] = *reinterpret_cast<const bf16x8 *>(dzn + (size_t)px * COUT + part * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < XC; ++k) {
+            const int c = tid + k * WG_THREADS, px = c / X_CHUNKS, part = c - px * X_CHUNKS;
+            if (c < P * X_CHUNKS) rx[k] = *reinterpret_cast<const bf16x8 *>(xn + (size_t)px * CINP + part * 8);
+        }
+    };
+    auto stage = [&]() {                                                 // registers -> LDS tiles (+ conv bias gradient on the way)
+#pragma unroll
+        for (int k = 0; k < DZC; ++k) {
+            const int c = tid + k * WG_THREADS, px = c / DZ_CHUNKS, part = c - px * DZ_CHUNKS;
+            if (c < P * DZ_CHUNKS && dz_mine) {
+                *reinterpret_cast<bf16x8 *>(dzt + px * DSTRIDE + part * 8) = rdz[k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zsum[j] += (float)rdz[k][j];
             }
         }
-        const bf16 *xn = x + (size_t)n * P * CINP;
-        for (int c = tid; c < P * X_CHUNKS; c += WG_THREADS) {
-            const int px = c / X_CHUNKS, part = c - px * X_CHUNKS;
-            *reinterpret_cast<bf16x8 *>(xt + pos_of(px) * XSTRIDE + part * 8) = *reinterpret_cast<const bf16x8 *>(xn + (size_t)px * CINP + part * 8);
+#pragma unroll
+        for (int k = 0; k < XC; ++k) {
+            const int c = tid + k * WG_THREADS, px = c / X_CHUNKS, part = c - px * X_CHUNKS;
+            if (c < P * X_CHUNKS) *reinterpret_cast<bf16x8 *>(xt + pos_of(px) * XSTRIDE + part * 8) = rx[k];
         }
-        __syncthreads();
+    };
+    auto mfmas = [&]() {
         if (active) {
 #pragma unroll
             for (int ks = 0; ks < 5; ++ks) {
@@ -670,6 +689,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_policy_wgrad(const bf16 *__restr
                         acc[mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b, acc[mi][t], 0, 0, 0);
                 }
             }
+        }
+    };
+
+    if (PF) {
+        if (sidx < N) fetch(sidx);
+        __syncthreads();                                                 // the zero fill is complete
+        for (int n = sidx; n < N; n += nslices) {
+            stage();                                                     // sample n: registers -> tiles
+            __syncthreads();
+            if (n + nslices < N) fetch(n + nslices);                     // sample n+1 in flight during the MFMAs of sample n
+            mfmas();
+            __syncthreads();                                             // all reads of the tiles are done
+        }
+    } else {
+        for (int n = sidx; n < N; n += nslices) {
+            __syncthreads();                                             // previous sample's reads are done (and the zero fill)
+            fetch(n);
+            stage();
+            __syncthreads();
+            mfmas();
         }
     }
     if (db) {                                                            // every dz element is loaded by exactly one block
@@ -827,7 +866,7 @@ extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const i
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }
 
-template <int CINP, int COUT, int MWW, int NBW>
+template <int CINP, int COUT, int MWW, int NBW, bool PF>
 static int launch_wgrad(const void *x, const void *dz, float *dw, float *db, int N, hipStream_t st)
 {
     constexpr int MS = MWW * (pol::WG_WAVES / NBW), Q = (COUT / 16 + MS - 1) / MS;
@@ -835,13 +874,14 @@ static int launch_wgrad(const void *x, const void *dz, float *dw, float *db, int
     constexpr size_t lds = (size_t)(pol::KPAD * DSTRIDE + pol::NPOS * XSTRIDE) * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_wgrad<CINP, COUT, MWW, NBW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return INV_ERR_HIP;
         attr_set = true;
     }
-    const int per_slice = trunk_grid(N) / Q > 0 ? trunk_grid(N) / Q : 1;             // two 8-wave blocks per CU (<= 126 VGPRs, <= 68 KB LDS)
+    const int blocks = PF ? trunk_grid(N) / 2 : trunk_grid(N);          // PF: one 8-wave block per CU; else two (<= 126 VGPRs, <= 68 KB LDS)
+    const int per_slice = blocks / Q > 0 ? blocks / Q : 1;
     const int nslices = N < per_slice ? N : per_slice;
-    hipLaunchKernelGGL((pol::k_policy_wgrad<CINP, COUT, MWW, NBW>), dim3(nslices * Q), dim3(pol::WG_THREADS), lds, st,
+    hipLaunchKernelGGL((pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF>), dim3(nslices * Q), dim3(pol::WG_THREADS), lds, st,
                        reinterpret_cast<const pol::bf16 *>(x), reinterpret_cast<const pol::bf16 *>(dz), dw, db, N);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }
@@ -852,10 +892,10 @@ extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *d
     if (N == 0) return INV_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (layer) {
-    case 0: return launch_wgrad<16, 32, 1, 1>(x_bf16, dz_bf16, dw, dbias, N, st);
-    case 1: return launch_wgrad<32, 64, 1, 2>(x_bf16, dz_bf16, dw, dbias, N, st);
-    case 2: return launch_wgrad<64, 128, 2, 4>(x_bf16, dz_bf16, dw, dbias, N, st);
-    default: return launch_wgrad<128, 128, 2, 8>(x_bf16, dz_bf16, dw, dbias, N, st);
+    case 0: return launch_wgrad<16, 32, 1, 1, false>(x_bf16, dz_bf16, dw, dbias, N, st);
+    case 1: return launch_wgrad<32, 64, 1, 2, false>(x_bf16, dz_bf16, dw, dbias, N, st);
+    case 2: return launch_wgrad<64, 128, 4, 4, true>(x_bf16, dz_bf16, dw, dbias, N, st);
+    default: return launch_wgrad<128, 128, 4, 8, true>(x_bf16, dz_bf16, dw, dbias, N, st);
     }
 }
 
