@@ -90,3 +90,10 @@ def test_algorithmic_bytes_match_survey():
     assert bench.algorithmic_bytes_per_env_step() == 7369            # SURVEY.md 8(d), 15x10 K=16 vs_dummy
     assert bench.algorithmic_bytes_per_env_step(selfplay=True) == 14585
     assert bench.algorithmic_bytes_per_env_step(32, 32, 16) == 49539
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" check: compiles (or finds up to date) the HIP library and the oracle, loads the
+    library and checks the ABI version against the header."""
+    import __graft_entry__ as g
+    g.build()
