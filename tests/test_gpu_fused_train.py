@@ -59,7 +59,7 @@ def test_training_forward_matches_inference_trunk_and_saves_consistent_tensors(n
     assert (lt - lm).abs().max() < 0.05 and (vt - vm).abs().max() < 0.05
 
 
-@pytest.mark.parametrize("n,packed", [(64, False), (333, True)])
+@pytest.mark.parametrize("n,packed", [(64, False), (333, True), (1300, True)])     # 1300 > 512 resident blocks: persistent loops
 def test_parameter_gradients_match_f32_autograd(n, packed):
     import torch
     from inversus_reinforcement_learning_amd.fused_train import FusedTrainPolicy
