@@ -180,3 +180,23 @@ def test_runner_torch_output_mode():
             assert inf_t[int(i)] == inf_n[int(i)]
     assert rt.episode_lengths == rn.episode_lengths and rt.episode_wins == rn.episode_wins
     rt.batch.check()
+
+
+def test_numpy_mode_returns_independent_arrays_every_step():
+    """The reference returns freshly stacked arrays from every step (env_wrappers.py:521-527); the pinned staging
+    blocks of the drop-in mode must not alias: what a caller kept from earlier steps stays what it was."""
+    from inversus_reinforcement_learning_amd.env_wrappers import MultiEnvRunner
+    n = 64
+    r = MultiEnvRunner(n, "dummy", "hard", seed=3, output="numpy", auto_reset=True, opp_seed=1)
+    r.reset()
+    rng = np.random.RandomState(1)
+    kept, copies = [], []
+    for t in range(12):
+        (g, x), rw, dn, infos = r.step(rng.randint(0, 13, n))
+        assert isinstance(g, np.ndarray) and g.dtype == np.float32 and g.shape == (n, 12, 10, 15) and g.flags.writeable
+        assert isinstance(infos, list) and len(infos) == n and set(infos[0]) == {"landed_hit", "got_hit", "win", "lose", "episode_steps", "episode_return"}
+        kept.append((g, x, rw, dn))
+        copies.append((g.copy(), x.copy(), rw.copy(), dn.copy()))
+    for (g, x, rw, dn), (g0, x0, rw0, dn0) in zip(kept, copies):
+        assert np.array_equal(g, g0) and np.array_equal(x, x0) and np.array_equal(rw, rw0) and np.array_equal(dn, dn0)
+    assert len({a[0].__array_interface__["data"][0] for a in kept}) == len(kept)          # 12 distinct buffers
