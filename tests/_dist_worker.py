@@ -20,12 +20,12 @@ class TinyPolicy(nn.Module):
     def __init__(self):
         super().__init__()
         self.body = nn.Linear(12 * 3 * 3 + 4, 32)
-        self.pi = nn.Linear(32, 13)
-        self.v = nn.Linear(32, 1)
+        self.fc_pi = nn.Linear(32, 13)          # "fc_" parameters = the early part of the gradient bucket (parallel.py)
+        self.fc_v = nn.Linear(32, 1)
 
     def forward(self, grid, extra):
         h = torch.tanh(self.body(torch.cat([grid.flatten(1), extra], 1)))
-        return self.pi(h), self.v(h)
+        return self.fc_pi(h), self.fc_v(h)
 
 
 def make_rollout(T, N, seed):
