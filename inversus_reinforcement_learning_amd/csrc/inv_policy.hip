@@ -73,11 +73,21 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define STAMP(slot) do { } while (0)
 #endif
 
+// Sum over the 64 lanes, result in every lane.  Rows of 16 lanes reduce with four DPP adds (quad swaps, half-row and row
+// mirror: VALU-only, no LDS crossbar); the four row sums are combined through readlane.  (__shfl_xor lowers to six
+// dependent ds_bpermute round trips per value.)
 __device__ __forceinline__ float wave_sum(float x)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+#define POL_DPP_ADD(ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+    POL_DPP_ADD(0xB1);                               // quad_perm [1,0,3,2]
+    POL_DPP_ADD(0x4E);                               // quad_perm [2,3,0,1]
+    POL_DPP_ADD(0x141);                              // row_half_mirror
+    POL_DPP_ADD(0x140);                              // row_mirror
+#undef POL_DPP_ADD
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // One conv3x3 (pad 1) + bias (+ residual) + LayerNorm over the whole sample + ReLU, as an implicit GEMM on
