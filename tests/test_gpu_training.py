@@ -159,3 +159,16 @@ def test_two_rank_training_rehearsal(fused):
         outs.append(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "TRAIN_OK" in out, f"rank {rank}:\\n{out[-3000:]}"
+
+
+def test_training_loop_on_the_32x32_board():
+    """BASELINE config C5's board through the whole loop (StaticDims<32,32,16> step kernel, the torch policy with its
+    131 076-input heads, HIP GAE): the wrapper of the reference cannot pass width / height (env_wrappers.py:264), the
+    mirror can."""
+    from inversus_reinforcement_learning_amd import training
+    res = training.train_vs_dummy(num_envs=32, total_steps=32 * 128, width=32, height=32, log_dir=None, opponent_difficulty="hard",
+                                  seed=1, verbose=False, agent_kwargs=dict(batch_size=1024, epochs=1))
+    assert res["steps"] == 32 * 128 and all(np.isfinite(res[k]) for k in ("policy_loss", "value_loss", "entropy"))
+    with pytest.raises(ValueError):                 # the fused policy kernels are 15 x 10 only and say so
+        training.train_vs_dummy(num_envs=8, total_steps=8 * 128, width=32, height=32, log_dir=None, seed=1, verbose=False,
+                                agent_kwargs=dict(fused_act=True))
