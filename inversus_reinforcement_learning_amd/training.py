@@ -195,7 +195,9 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=None)
     # not in the reference: the fused MI355X paths and the PPO settings that make sense at thousands of envs
     ap.add_argument("--fused", action="store_true",
-                    help="rollout forwards AND the PPO update's trunk forward/backward in the fused bf16 HIP kernels")
+                    help="rollout forwards AND the PPO update's trunk forward/backward in the fused bf16 HIP kernels "
+                         "(at thousands of envs also pass --batch_size, e.g. 16384: the reference default of 512 means "
+                         "thousands of tiny optimizer steps per rollout)")
     ap.add_argument("--batch_size", type=int, default=None, help="PPO minibatch size (reference default 512)")
     ap.add_argument("--epochs", type=int, default=None, help="PPO epochs per rollout (reference default 4)")
     ap.add_argument("--lr", type=float, default=None)
