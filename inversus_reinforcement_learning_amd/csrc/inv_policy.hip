@@ -202,7 +202,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     const float var = fmaxf(SS / cnt - mean * mean, 0.0f);
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
     const float shift = -mean * rstd;
-    if (SAVE && threadIdx.x == 0) *sv.rstd = rstd;
+    if (SAVE && sv.rstd && threadIdx.x == 0) *sv.rstd = rstd;
 
     if constexpr (SAVE) {
         // Training forward: x^ (rounded to bf16) goes into the tile in place of the activation, then ONE row pass by all
@@ -228,7 +228,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             const int p = q / (COUT / 8), part = q - p * (COUT / 8);
             bf16 *tp = tile + pos_of(p) * CSTRIDE + part * 8;
             const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(tp);
-            xdst[q] = xv;
+            if (xdst) xdst[q] = xv;
             const _Float16 *lq = reinterpret_cast<const _Float16 *>(lp.ln) + ((size_t)p * COUT + part * 8) * 2;
             const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
             bf16x8 o;
@@ -359,15 +359,16 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
         // waves), which also leaves the register allocator enough room to keep the epilogue out of scratch.
         if (SAVE) {
             const size_t sn = (size_t)n * P;
-            bf16 *const xh0 = reinterpret_cast<bf16 *>(sv.xhat[0]) + sn * 32, *const xh1 = reinterpret_cast<bf16 *>(sv.xhat[1]) + sn * 64;
-            bf16 *const xh2 = reinterpret_cast<bf16 *>(sv.xhat[2]) + sn * 128, *const xh3 = reinterpret_cast<bf16 *>(sv.xhat[3]) + sn * 128;
-            bf16 *const ac0 = reinterpret_cast<bf16 *>(sv.act[0]) + sn * 32, *const ac1 = reinterpret_cast<bf16 *>(sv.act[1]) + sn * 64;
-            bf16 *const ac2 = reinterpret_cast<bf16 *>(sv.act[2]) + sn * 128;
-            float *const rs = sv.rstd + (size_t)n * 4;
+            const bool keep = sv.rstd != nullptr;       // saved == NULL: the training NUMERICS (x^ rounded to bf16) without the stores
+            bf16 *const xh0 = keep ? reinterpret_cast<bf16 *>(sv.xhat[0]) + sn * 32 : nullptr, *const xh1 = keep ? reinterpret_cast<bf16 *>(sv.xhat[1]) + sn * 64 : nullptr;
+            bf16 *const xh2 = keep ? reinterpret_cast<bf16 *>(sv.xhat[2]) + sn * 128 : nullptr, *const xh3 = keep ? reinterpret_cast<bf16 *>(sv.xhat[3]) + sn * 128 : nullptr;
+            bf16 *const ac0 = keep ? reinterpret_cast<bf16 *>(sv.act[0]) + sn * 32 : nullptr, *const ac1 = keep ? reinterpret_cast<bf16 *>(sv.act[1]) + sn * 64 : nullptr;
+            bf16 *const ac2 = keep ? reinterpret_cast<bf16 *>(sv.act[2]) + sn * 128 : nullptr;
+            float *const rs = keep ? sv.rstd + (size_t)n * 4 : nullptr;
             conv_ln_relu<32, 32, 1, 5, false, false, true>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0, LayerSave{ xh0, ac0, rs });
-            conv_ln_relu<32, 64, 1, 10, false, false, true>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1, LayerSave{ xh1, ac1, rs + 1 });
-            conv_ln_relu<64, 128, 4, 5, false, false, true>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2, LayerSave{ xh2, ac2, rs + 2 });
-            conv_ln_relu<128, 128, 4, 5, false, true, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3, LayerSave{ xh3, nullptr, rs + 3 });
+            conv_ln_relu<32, 64, 1, 10, false, false, true>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1, LayerSave{ xh1, ac1, keep ? rs + 1 : nullptr });
+            conv_ln_relu<64, 128, 4, 5, false, false, true>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2, LayerSave{ xh2, ac2, keep ? rs + 2 : nullptr });
+            conv_ln_relu<128, 128, 4, 5, false, true, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3, LayerSave{ xh3, nullptr, keep ? rs + 3 : nullptr });
         } else {
         conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
         conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
@@ -852,15 +853,18 @@ static bool saved_ok(const inv_policy_saved *sv)
 extern "C" int inv_policy_trunk_train_fwd(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, void *feat_bf16,
                                           const inv_policy_saved *saved, int32_t N, void *stream)
 {
-    if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params) || !saved_ok(saved)) return INV_ERR_BAD_ARG;
+    if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params) || (saved && !saved_ok(saved))) return INV_ERR_BAD_ARG;
     if (N == 0) return INV_OK;
     const int grid = trunk_grid(N);
+    inv_policy_saved sv;
+    memset(&sv, 0, sizeof sv);                       // saved == NULL: same numerics, nothing stored (rollouts that a fused update follows)
+    if (saved) sv = *saved;
     if (obs_is_bits)
         hipLaunchKernelGGL((pol::k_policy_trunk<true, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
-                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, *saved);
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, sv);
     else
         hipLaunchKernelGGL((pol::k_policy_trunk<false, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
-                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, *saved);
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, sv);
     return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
 }
 

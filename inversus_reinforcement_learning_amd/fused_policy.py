@@ -31,8 +31,12 @@ def _pack_conv(w, cin_pad):
 class FusedPolicy:
     """Callable like the module in eval mode: (grid f32 [B,12,10,15] or packed int32 [B,57], extra f32 [B,4]) -> (logits, value)."""
 
-    def __init__(self, policy):
+    def __init__(self, policy, train_numerics=False):
+        """train_numerics: run the trunk with the numerics of the fused UPDATE's forward (x^ rounded to bf16 before the
+        LayerNorm affine, csrc/inv_policy.hip SAVE path) instead of the slightly more accurate inference epilogue, so that
+        log-probs / values stored during rollouts are what the update's first forward recomputes (PPO ratio = 1)."""
         self.policy = policy
+        self.train_numerics = bool(train_numerics)
         self.lib = L.load()
         self.refresh()
 
@@ -78,8 +82,12 @@ class FusedPolicy:
             grid, fn = grid.contiguous().float(), self.lib.inv_policy_trunk
         feat = torch.empty((grid.shape[0], 19200), dtype=torch.bfloat16, device=grid.device)
         with torch.cuda.device(grid.device):
-            rc = fn(C.byref(self.params), C.c_void_p(grid.data_ptr()), C.c_void_p(feat.data_ptr()),
-                    grid.shape[0], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if self.train_numerics:
+                rc = self.lib.inv_policy_trunk_train_fwd(C.byref(self.params), C.c_void_p(grid.data_ptr()), int(grid.dtype == torch.int32),
+                                                         C.c_void_p(feat.data_ptr()), None, grid.shape[0], st)
+            else:
+                rc = fn(C.byref(self.params), C.c_void_p(grid.data_ptr()), C.c_void_p(feat.data_ptr()), grid.shape[0], st)
         L.raise_for(rc, self.lib)
         return feat
 

@@ -53,7 +53,9 @@ class PPOAgent:
         self.fused = None
         if fused_act:
             from .fused_policy import FusedPolicy
-            self.fused = FusedPolicy(self.policy)
+            # with the fused update the rollout forward uses the update's numerics: the stored log-probs / values are
+            # then what the first minibatch recomputes, and the PPO ratio starts at 1 instead of 1 +- 1e-2
+            self.fused = FusedPolicy(self.policy, train_numerics=fused_update)
         self.reset_buffers()
 
     # ------------------------------------------------------------------ buffers (ppo_agent.py:58-66, 108-125)

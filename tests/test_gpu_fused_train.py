@@ -153,3 +153,33 @@ def test_ppo_update_with_fused_trunk_tracks_torch_update():
     # Adam's first step is lr * sign-like: compare directions
     cos = float(torch.nn.functional.cosine_similarity(deltas[0], deltas[1], dim=0))
     assert cos > 0.9, cos
+
+
+def test_rollout_forward_uses_the_updates_numerics_when_the_update_is_fused():
+    """PPOAgent(fused_act=True, fused_update=True): log-probs / values stored by act() are what the update's first
+    forward recomputes on the same observations (PPO ratio starts at 1); with the inference epilogue they differ ~1e-2."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    n, T = 256, 6
+    torch.manual_seed(0)
+    b = DeviceEnvBatch(n, opponent="dummy", difficulty="hard", opp_seed=2)
+    b.seed(np.arange(n, dtype=np.int64)); b.reset()
+    pol = _policy(5)
+    agent = PPOAgent(pol, fused_act=True, fused_update=True, batch_size=n * T, epochs=1)
+    assert agent.fused.train_numerics
+    RolloutCollector(b, agent).collect(T)
+    grid, extra = torch.cat(agent.obs_grid_buffer), torch.cat(agent.obs_extra_buffer)
+    acts, old_lp, old_v = torch.cat(agent.action_buffer), torch.cat(agent.log_prob_buffer), torch.cat(agent.value_buffer)
+    with torch.no_grad():
+        lo, v = agent.train_fwd(grid, extra)
+        new_lp = torch.distributions.Categorical(logits=lo.float(), validate_args=False).log_prob(acts)
+        # identical trunk features; the heads' GEMMs run at another batch size (other tiling / summation order): ~1e-5
+        assert float((new_lp - old_lp).abs().max()) < 2e-4 and float((v.float().squeeze(-1) - old_v).abs().max()) < 2e-4
+        assert float((new_lp - old_lp).abs().mean()) < 1e-5
+        lo_i, _ = FusedPolicy(pol)(grid, extra)                  # inference epilogue: close, but not the same numbers
+        lp_i = torch.distributions.Categorical(logits=lo_i.float(), validate_args=False).log_prob(acts)
+        assert 5e-4 < float((lp_i - old_lp).abs().max()) < 0.1
