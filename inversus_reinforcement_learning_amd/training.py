@@ -100,6 +100,9 @@ class RolloutCollector:
 
 def _make(num_envs_total, opponent_type, difficulty, seed, width, height):
     rank, world_size = parallel.init_from_env()
+    if world_size > 1 and num_envs_total % world_size:
+        # every rank must run the same number of minibatches: each optimizer step is one gradient all-reduce
+        raise ValueError(f"num_envs ({num_envs_total}) must be divisible by the number of ranks ({world_size})")
     offset, count = parallel.shard_range(num_envs_total, rank, world_size)
     base = int.from_bytes(os.urandom(7), "little") if seed is None else int(seed)
     if world_size > 1 and seed is None:
