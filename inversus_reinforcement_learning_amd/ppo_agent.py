@@ -140,9 +140,14 @@ class PPOAgent:
         return adv.cpu().numpy(), ret.cpu().numpy()
 
     # ------------------------------------------------------------------ update (ppo_agent.py:159-247)
-    def update(self, advantages=None, returns=None):
+    def update(self, advantages=None, returns=None, *, permutations=None, trace=False):
         """PPO update over the stored rollout.  `advantages` / `returns` (flat, buffer order) may be
-        supplied by the caller; by default they come from the HIP GAE kernel."""
+        supplied by the caller; by default they come from the HIP GAE kernel.
+        permutations: one index permutation of the T*N samples per epoch (what the reference's
+        `np.random.shuffle(indices)` leaves in `indices`, ppo_agent.py:195) -- the injection hook of the parity
+        fixture tests/golden/g8_ppo_update.npz; default: torch.randperm on the device.
+        trace: also return the per-minibatch policy / value loss, entropy and pre-clip gradient norm
+        (`stats["minibatches"]`, f64 arrays) and the normalised advantages (`stats["advantages"]`)."""
         if len(self.obs_grid_buffer) == 0:
             return {}
         if advantages is None:
@@ -164,8 +169,16 @@ class PPOAgent:
         num_samples = obs_grid.shape[0]
         num_updates = 0
         params = [p for p in self.policy.parameters() if p.requires_grad]
-        for _ in range(self.epochs):
-            indices = torch.randperm(num_samples, device=self.device)
+        if permutations is not None and len(permutations) != self.epochs:
+            raise ValueError(f"permutations: expected {self.epochs} (one per epoch), got {len(permutations)}")
+        mb_trace = []
+        for epoch in range(self.epochs):
+            if permutations is None:
+                indices = torch.randperm(num_samples, device=self.device)
+            else:
+                indices = torch.as_tensor(permutations[epoch], dtype=torch.int64, device=self.device).reshape(-1)
+                if indices.numel() != num_samples:
+                    raise ValueError(f"permutations[{epoch}] must index all {num_samples} samples")
             for start in range(0, num_samples, self.batch_size):
                 idx = indices[start:start + self.batch_size]
                 if self.train_fwd is not None:                            # fused trunk kernels; reads packed observations as is
@@ -192,8 +205,10 @@ class PPOAgent:
                 else:
                     self.optimizer.zero_grad()
                     loss.backward()
-                torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                grad_norm = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
                 self.optimizer.step()
+                if trace:
+                    mb_trace.append(torch.stack([policy_loss.detach(), value_loss.detach(), entropy.detach(), grad_norm.detach()]))
                 tot_p += policy_loss.detach()
                 tot_v += value_loss.detach()
                 tot_e += entropy.detach()
@@ -201,5 +216,10 @@ class PPOAgent:
         self.reset_buffers()
         if self.fused is not None:
             self.fused.refresh()                                          # re-pack the updated weights for the actor
-        return {"policy_loss": float(tot_p) / num_updates, "value_loss": float(tot_v) / num_updates,
-                "entropy": float(tot_e) / num_updates}
+        stats = {"policy_loss": float(tot_p) / num_updates, "value_loss": float(tot_v) / num_updates,
+                 "entropy": float(tot_e) / num_updates}
+        if trace:
+            m = torch.stack(mb_trace).double().cpu().numpy()
+            stats["minibatches"] = {"policy_loss": m[:, 0], "value_loss": m[:, 1], "entropy": m[:, 2], "grad_norm": m[:, 3]}
+            stats["advantages"] = advantages.detach().cpu().numpy()
+        return stats

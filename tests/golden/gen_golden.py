@@ -129,10 +129,30 @@ def gen_core_trace(name, W, H, E, T, base_seed, act_seed, biased):
 
 
 # --------------------------------------------------------------------------- G3
-def gen_wrapper_trace(name, W, H, E, T, base_seed, act_seed, biased, max_steps):
+def hunt_action(env, pid):
+    """An action id that closes in on the enemy: shoot along the shared row / column, else step towards alignment along the
+    shorter axis (shooting the way open first: a player only walks on tiles of the other colour).  Only used to CHOOSE the
+    recorded action streams of a fixture (so that a big board sees kills); parity replays the recorded ids."""
+    me, en = (env.player1, env.player2) if pid == PlayerId.P1 else (env.player2, env.player1)
+    dx, dy = en.x - me.x, en.y - me.y
+    if dx == 0 and dy == 0:
+        return 0
+    if dx == 0:
+        return 5 + (0 if dy < 0 else 2)
+    if dy == 0:
+        return 5 + (3 if dx < 0 else 1)
+    if abs(dx) <= abs(dy):
+        d, nx, ny = (3 if dx < 0 else 1), me.x + (-1 if dx < 0 else 1), me.y
+    else:
+        d, nx, ny = (0 if dy < 0 else 2), me.x, me.y + (-1 if dy < 0 else 1)
+    return (1 if env._is_walkable_for_player(nx, ny, me.color) else 5) + d
+
+
+def gen_wrapper_trace(name, W, H, E, T, base_seed, act_seed, biased, max_steps, hunt=(0.0, 0.0)):
     rng = np.random.RandomState(act_seed)
     a1 = action_stream(rng, (T, E), biased)
     a2 = action_stream(rng, (T, E), biased)
+    hunt_draw = rng.random_sample((T, E, 2)) if max(hunt) > 0 else None
     envs = []
     for i in range(E):
         w = ew.SingleInversusRLEnv(opponent_type="selfplay", max_episode_steps=max_steps, seed=base_seed + i)
@@ -159,6 +179,11 @@ def gen_wrapper_trace(name, W, H, E, T, base_seed, act_seed, biased, max_steps):
     for t in range(T):
         for i, w in enumerate(envs):
             seen = {}
+            if hunt_draw is not None:            # the streams are recorded below, after the loop filled them in
+                if hunt_draw[t, i, 0] < hunt[0]:
+                    a1[t, i] = hunt_action(w.env, PlayerId.P1)
+                if hunt_draw[t, i, 1] < hunt[1]:
+                    a2[t, i] = hunt_action(w.env, PlayerId.P2)
 
             def opp(obs, _i=i, _t=t, _seen=seen):
                 _seen["g"], _seen["x"] = obs
@@ -357,7 +382,127 @@ def gen_arbitrary(n_cases=1500, W=15, H=10):
     print("g7: cases", n_cases, "dones", int(arr["o_done"].sum()), "max bullets after", int(arr["o_nbullets"].max()))
 
 
+# --------------------------------------------------------------------------- G8
+def gen_ppo_update():
+    """PPOAgent.update (ppo_agent.py:159-247) on a small rollout collected by the reference's own loop
+    (training.py:117-157): 4 envs x 32 steps vs the hard dummy, `torch.manual_seed(0)` policy (the G5 init).
+    The update is observed, not re-stated: np.random.shuffle / torch.FloatTensor / torch.min / mse_loss /
+    Categorical.entropy / clip_grad_norm_ are wrapped for the duration of the call and record what the
+    reference passed through them (permutation per epoch, normalised advantages, returns, per-minibatch
+    policy / value loss, entropy, pre-clip gradient norm); every wrapper returns the real result."""
+    import copy
+    import torch
+    from inversus_rl.ppo_agent import PPOAgent
+    from inversus_rl.policies import InversusCNNPolicy
+    N, T = 4, 32
+    random.seed(5)
+    np.random.seed(11)
+    torch.manual_seed(0)
+    policy0 = InversusCNNPolicy(12, 10, 15, 4)
+    runner = ew.MultiEnvRunner(N, "dummy", "hard", max_episode_steps=12, seed=4242)
+    agent = PPOAgent(policy0)
+    obs_grid, obs_extra = runner.reset()
+    for _ in range(T):                                           # training.py:119-153
+        actions, log_probs, values = agent.act(obs_grid, obs_extra)
+        (ng, nx), rewards, dones, infos = runner.step(actions)
+        for i in range(N):
+            agent.store_step(obs_grid[i], obs_extra[i], int(actions[i]), float(log_probs[i]), float(values[i]),
+                             float(rewards[i]), bool(dones[i]))
+            if dones[i]:
+                g, x = runner.envs[i].reset()
+                ng[i], nx[i] = g, x
+        obs_grid, obs_extra = ng, nx
+    buf = dict(obs=np.stack([obs_bits(g) for g in agent.obs_grid_buffer]),
+               extra=np.stack(agent.obs_extra_buffer).astype(np.float32),
+               actions=np.array(agent.action_buffer, np.int64),
+               log_probs=np.array(agent.log_prob_buffer, np.float32),        # float(f32) round-trips exactly
+               values=np.array(agent.value_buffer, np.float32),
+               rewards=np.array(agent.reward_buffer, np.float32),
+               dones=np.array(agent.done_buffer, np.uint8))
+    for k in ("log_probs", "values", "rewards"):
+        assert np.array_equal(buf[k].astype(np.float64), np.array(getattr(agent, {"log_probs": "log_prob_buffer", "values": "value_buffer",
+                                                                              "rewards": "reward_buffer"}[k]), np.float64))
+    out = {"N": N, "T": T, **buf}
+    adv_raw, ret_raw = agent.compute_advantages()
+    out["adv_flat"], out["ret_flat"] = adv_raw, ret_raw
+    sd0 = {k: v.clone() for k, v in policy0.state_dict().items()}
+
+    for case, epochs, batch in (("e1_full", 1, N * T), ("e2_b32", 2, 32)):
+        pol = InversusCNNPolicy(12, 10, 15, 4)
+        pol.load_state_dict(sd0)
+        ag = PPOAgent(pol, epochs=epochs, batch_size=batch)
+        for name in ("obs_grid_buffer", "obs_extra_buffer", "action_buffer", "log_prob_buffer", "reward_buffer",
+                     "value_buffer", "done_buffer"):
+            setattr(ag, name, copy.deepcopy(getattr(agent, name)))
+        rec = {"perm": [], "ft": [], "pol": [], "val": [], "ent": [], "gn": []}
+        real = (np.random.shuffle, torch.FloatTensor, torch.min, torch.nn.functional.mse_loss,
+                torch.distributions.Categorical.entropy, torch.nn.utils.clip_grad_norm_)
+
+        def shuffle(x):
+            real[0](x)
+            rec["perm"].append(np.array(x, np.int64))
+
+        def float_tensor(x):
+            t = real[1](x)
+            rec["ft"].append(t.clone())
+            return t
+
+        def tmin(a, b):
+            r = real[2](a, b)
+            rec["pol"].append(float(-r.mean()))
+            return r
+
+        def mse(a, b):
+            r = real[3](a, b)
+            rec["val"].append(float(r))
+            return r
+
+        def entropy(self):
+            r = real[4](self)
+            rec["ent"].append(float(r.mean()))
+            return r
+
+        def clip(params, max_norm):
+            r = real[5](params, max_norm)
+            rec["gn"].append(float(r))
+            return r
+
+        np.random.seed(1000 + epochs)
+        np.random.shuffle, torch.FloatTensor, torch.min = shuffle, float_tensor, tmin
+        torch.nn.functional.mse_loss, torch.distributions.Categorical.entropy = mse, entropy
+        torch.nn.utils.clip_grad_norm_ = clip
+        try:
+            stats = ag.update()
+        finally:
+            (np.random.shuffle, torch.FloatTensor, torch.min, torch.nn.functional.mse_loss,
+             torch.distributions.Categorical.entropy, torch.nn.utils.clip_grad_norm_) = real
+        n_mb = epochs * -(-N * T // batch)
+        assert len(rec["perm"]) == epochs and len(rec["ft"]) == 5 and all(len(rec[k]) == n_mb for k in ("pol", "val", "ent", "gn"))
+        sd1 = pol.state_dict()
+        out[f"{case}_epochs"], out[f"{case}_batch"] = epochs, batch
+        out[f"{case}_perm"] = np.stack(rec["perm"])
+        out[f"{case}_adv_norm"] = rec["ft"][3].numpy()          # (A - mean) / (std + 1e-8), ppo_agent.py:173
+        out[f"{case}_returns"] = rec["ft"][4].numpy()
+        for k, name in (("pol", "mb_policy_loss"), ("val", "mb_value_loss"), ("ent", "mb_entropy"), ("gn", "mb_grad_norm")):
+            out[f"{case}_{name}"] = np.array(rec[k], np.float64)
+        out[f"{case}_stats"] = np.array([stats["policy_loss"], stats["value_loss"], stats["entropy"]], np.float64)
+        out[f"{case}_sums"] = np.array([float(v.double().sum()) for v in sd1.values()])
+        out[f"{case}_abs_sums"] = np.array([float(v.double().abs().sum()) for v in sd1.values()])
+        out[f"{case}_delta_sums"] = np.array([float((sd1[k].double() - sd0[k].double()).sum()) for k in sd1])
+        out[f"{case}_delta_abs_sums"] = np.array([float((sd1[k].double() - sd0[k].double()).abs().sum()) for k in sd1])
+        print(f"g8 {case}: stats {stats} grad norms {rec['gn'][:3]} dones {int(buf['dones'].sum())}")
+    out["keys"] = np.array(list(sd0.keys()))
+    np.savez_compressed(os.path.join(OUT, "g8_ppo_update.npz"), **out)
+
+
 def main():
+    only = set(sys.argv[1:])                     # e.g. `gen_golden.py g8 g3_32` regenerates just those
+    if only:
+        if "g8" in only:
+            gen_ppo_update()
+        if "g3_32" in only:
+            gen_wrapper_trace("32x32_biased", 32, 32, 8, 384, base_seed=900, act_seed=203, biased=True, max_steps=150, hunt=(0.6, 0.45))
+        return
     gen_spawn(15, 10)
     gen_spawn(32, 32)
     gen_spawn(3, 3)
@@ -368,11 +513,12 @@ def main():
     gen_wrapper_trace("15x10_uniform", 15, 10, 32, 512, base_seed=0, act_seed=200, biased=False, max_steps=500)
     gen_wrapper_trace("15x10_biased", 15, 10, 32, 512, base_seed=500, act_seed=201, biased=True, max_steps=500)
     gen_wrapper_trace("15x10_timeout20", 15, 10, 16, 128, base_seed=700, act_seed=202, biased=False, max_steps=20)
-    gen_wrapper_trace("32x32_biased", 32, 32, 8, 256, base_seed=900, act_seed=203, biased=True, max_steps=100)
+    gen_wrapper_trace("32x32_biased", 32, 32, 8, 384, base_seed=900, act_seed=203, biased=True, max_steps=150, hunt=(0.6, 0.45))
     gen_gae()
     gen_dummy()
     gen_policy()
     gen_arbitrary()
+    gen_ppo_update()
 
 
 if __name__ == "__main__":
