@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N child ranks (fresh
+processes, started before this process makes any GPU call; never an exec of a process that touched the GPU); under an
+external torchrun the ranks are used as given.  Either way it is one process per GPU over RCCL (backend "nccl").
+
 One "step" = one vector step of the shard's 16 384 envs: P1 actions from a synthetic stream (device
 Philox, the stand-in for the policy in BASELINE.json configs[1] "HIP step + obs kernels only";
 generated before the timed region), device dummy opponent, core tick, reward/done/info, auto-reset, 12-channel observation render.
@@ -47,12 +51,31 @@ def traffic_from_profiles(difficulty):
         return None
 
 
-def cpu_baseline(difficulty, budget_s=12.0):
-    """The C oracle (bit-checked against the reference) on the host cores: same seeds, same
-    action stream, same config; bounded sample."""
+def host_threads():
+    """Threads this job may actually use: the scheduler affinity, further limited by a cgroup CPU quota if one is set."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    return aff, quota
+
+
+def cpu_baseline(difficulty, budget_s=8.0):
+    """The C oracle (bit-checked against the reference) on the host cores: same seeds, same action stream, same
+    config; bounded sample.  Threads = what the job may use (affinity / cgroup quota, both reported), the output
+    buffers are allocated once and first touched inside the OpenMP region (each thread faults in the pages it writes)."""
     import numpy as np
     from oracle import oracle as orc
-    cores = min(os.cpu_count() or 1, 16)
+    aff, quota = host_threads()
+    cores = min(aff, quota) if quota else aff
     L = orc.lib()
     hard = difficulty == "hard"
 
@@ -60,10 +83,11 @@ def cpu_baseline(difficulty, budget_s=12.0):
         ob = orc.OracleBatch(n, W, H)
         ob.seed_reset(np.arange(n, dtype=np.int64))
         acts = [np.array([L.orc_uniform_action(1234, i, t) for i in range(n)], np.uint8) for t in range(4)]
-        ob.step(acts[0], None, hard=hard, opp_seed=1, nthreads=threads)          # warm-up
+        bufs = ob.alloc_out()
+        ob.step(acts[0], None, hard=hard, opp_seed=1, nthreads=threads, out=bufs)          # warm-up + first touch
         steps, t0 = 0, time.perf_counter()
         while True:
-            ob.step(acts[steps % 4], None, hard=hard, opp_seed=1, nthreads=threads)
+            ob.step(acts[steps % 4], None, hard=hard, opp_seed=1, nthreads=threads, out=bufs)
             steps += 1
             dt = time.perf_counter() - t0
             if dt > budget or steps >= 20000:
@@ -92,6 +116,9 @@ def cpu_baseline(difficulty, budget_s=12.0):
 
     v, steps = run(NUM_ENVS, cores, budget_s)
     v1, _ = run(NUM_ENVS, 1, 3.0)
+    scaling = {"1": round(v1), str(cores): round(v)}
+    if cores > 16:
+        scaling["16"] = round(run(NUM_ENVS, 16, 3.0)[0])
     v4, _ = run(4, 1, 1.0)
     vpy = python_loop(4, 1.0)
     model = ""
@@ -101,10 +128,12 @@ def cpu_baseline(difficulty, budget_s=12.0):
     except OSError:
         pass
     return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} vector steps x {NUM_ENVS} envs, vs_dummy_{difficulty}, C oracle (OpenMP over envs), obs rendered",
+            "sample": f"{steps} vector steps x {NUM_ENVS} envs, vs_dummy_{difficulty}, C oracle (OpenMP over envs, static schedule, "
+                      "buffers reused and first-touched in the parallel region), obs rendered",
+            "env_steps_per_s_by_threads": scaling, "speedup_all_threads_vs_one": round(v / v1, 2),
             "one_core_env_steps_per_s": round(v1), "n4_one_core_env_steps_per_s": round(v4),
             "n4_python_object_loop_env_steps_per_s": round(vpy),
-            "host": {"cpu_model": model, "nproc": os.cpu_count()}}
+            "host": {"cpu_model": model, "nproc": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota": quota}}
 
 
 def side_measurements(torch, np, n):
@@ -159,6 +188,25 @@ def side_measurements(torch, np, n):
     guard("step selfplay 15x10 (P1+P2 obs)", step_cfg(15, 10, "selfplay", "easy", True, True))
     guard("step vs_dummy_hard 32x32 K=16 (C5)", step_cfg(32, 32, "dummy", "hard", False, False))
     guard("step selfplay 15x10, PACKED P1+P2 obs (INV_STEP_OBS_BITS)", step_cfg(15, 10, "selfplay", "easy", True, True, bits=True))
+
+    def rollout_cfg(T=32):
+        """The persistent multi-step variant: T vector steps in ONE launch (inv_rollout) against T single launches."""
+        b = DeviceEnvBatch(n, 15, 10, K, opponent="dummy", difficulty="easy", opp_seed=1)
+        b.seed(np.arange(n, dtype=np.int64)); b.reset()
+        a1 = torch.stack([b.uniform_actions(7, t) for t in range(T)])
+        o = b._alloc_out((T,), True, False, False, None)
+        us = timed(lambda: b.rollout(a1, out=o), 6, warm=2) / T
+        o1 = b._alloc_out((), True, False, False, None)
+        stp = b.make_stepper(o1, None, auto_reset=True)
+        k = [0]
+
+        def single():
+            stp(a1[k[0] % T].data_ptr()); k[0] += 1
+        us1 = timed(single, 6 * T, warm=T)
+        by = algorithmic_bytes_per_env_step() * n
+        return {"T": T, "us_per_vector_step_in_one_launch": round(us, 2), "GBps": round(by / us / 1e3, 1),
+                "us_per_vector_step_single_launches": round(us1, 2), "GBps_single_launches": round(by / us1 / 1e3, 1)}
+    guard("inv_rollout vs_dummy_easy 15x10 (T steps per launch)", rollout_cfg)
 
     def gae_cfg():
         T = 128
@@ -222,11 +270,54 @@ def side_measurements(torch, np, n):
     return out
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N fresh child ranks of this script (one per GPU) and wait.
+    The parent has not imported torch or touched the GPU, and it never execs: the children are new processes that
+    inherit stdout (rank 0 prints the JSON line).  Returns the exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                # dmabuf IPC (RCCL across processes on this driver)
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + 1500
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:                                        # a dead rank leaves the others in a collective
+                        q.terminate()
+            if time.time() > deadline:
+                rc = rc or 124
+                for q in procs:
+                    q.terminate()
+                deadline = float("inf")
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps vector steps each; the line reports the MEDIAN region (SURVEY 8d: median of 5)")
     ap.add_argument("--difficulty", default="easy", choices=["easy", "hard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
@@ -234,7 +325,12 @@ def main():
                     help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: put every rank on GPU 0 (a 1-GPU box cannot give each rank its own GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even for one rank (runs the RCCL code path on a 1-GPU box)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:                 # no launcher: be the launcher (before any GPU call)
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -245,15 +341,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     dev = 0 if args.share_device else local_rank
+    if dev >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); "
+                         "--share-device rehearses N ranks on one GPU")
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group("gloo")
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     n = NUM_ENVS
     off = rank * n                                   # contiguous global env range per rank
@@ -261,7 +365,8 @@ def main():
     b.seed(off + np.arange(n, dtype=np.int64))       # seed = base 0 + global env index
     b.reset()
     out = b._alloc_out((), True, False, False, None)  # fixed output buffers: no allocator in the loop
-    # the synthetic P1 action stream of every step is generated BEFORE the timed region (inputs resident in HBM)
+    # the synthetic P1 action stream of every step is generated BEFORE the timed region (inputs resident in HBM);
+    # every repeat replays the same K action rows on the env state the previous region left behind
     total = args.warmup + args.steps
     a1_all = torch.empty((total, n), dtype=torch.uint8, device="cuda")
     for t in range(total):
@@ -274,39 +379,54 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def max_over_ranks(x):
-        if world == 1:
+    def over_ranks(x, op):
+        if not use_dist:
             return x
-        tt = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tt = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=op)
         return float(tt.item())
+
+    def gather(x):
+        """x of every rank, in rank order, on every rank."""
+        if not use_dist:
+            return [float(x)]
+        v = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        v[rank] = float(x)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        return [float(t) for t in v.tolist()]
 
     # HIP events on the launch stream around groups of EV_GROUP consecutive k_step launches (an event
     # pair per launch costs ~2 us of queue markers per step); kernel_ms = group time / launches, so it
     # includes the ~1.5 us dependent-launch boundary between steps of one env batch.
     groups = [(k, min(k + EV_GROUP, args.steps)) for k in range(0, args.steps, EV_GROUP)]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
-    fence()
-    t0 = time.perf_counter()
-    for (lo, hi), (e0, e1) in zip(groups, ev):
-        e0.record()
-        for k in range(lo, hi):
-            step(base + (args.warmup + k) * n)
-        e1.record()
-    fence()
-    dt = time.perf_counter() - t0
+    regions = []                                     # (wall seconds max over ranks, kernel ms of this rank) per repeat
+    for _ in range(max(1, args.repeats)):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
+        fence()
+        t0 = time.perf_counter()
+        for (lo, hi), (e0, e1) in zip(groups, ev):
+            e0.record()
+            for k in range(lo, hi):
+                step(base + (args.warmup + k) * n)
+            e1.record()
+        fence()
+        dt = time.perf_counter() - t0
+        regions.append((over_ranks(dt, dist.ReduceOp.MAX), sum(s.elapsed_time(e) for s, e in ev) / args.steps))
     b.check()
 
-    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / args.steps
-    dt = max_over_ranks(dt)
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    med = order[len(order) // 2]                     # the median region by wall time (max over ranks)
+    dt, kern_ms = regions[med]
+    kern_ms_ranks = gather(kern_ms)                  # the same region's k_step time on every rank: a slow rank is visible
 
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_env_step() * n
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        kern_ms_roof = sorted(kern_ms_ranks)[len(kern_ms_ranks) // 2]
+        achieved = bytes_per_launch / (kern_ms_roof * 1e-3) / 1e9
         res = {
             "metric": "env-steps/sec at 16384 envs per MI355X",
             "value": world * n * args.steps / dt,
@@ -322,20 +442,23 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"vs_dummy_{args.difficulty}: {n} envs/GPU, 15x10 grid, K=16, step+obs kernels only "
                                    "(Philox a1 stream, device dummy a2, reward/done, auto-reset, 12-ch obs)",
-                       "envs_per_gpu": n, "sharding": f"env-shards x{world}, no data-path collective"},
+                       "envs_per_gpu": n, "sharding": f"env-shards x{world}, no data-path collective",
+                       "backend": (args.backend if use_dist else "none")},
+            "repeats": len(regions), "protocol": "median of the repeats' wall time (each = exactly `steps` vector steps, barrier + synchronize on both sides)",
+            "ms_per_step_repeats": [round(r[0] / args.steps * 1e3, 6) for r in regions],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(args.difficulty),
-                         "kernel": "k_step", "kernel_ms": kern_ms,
+                         "kernel": "k_step", "kernel_ms": kern_ms_roof, "kernel_ms_per_rank": [round(x, 6) for x in kern_ms_ranks],
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step()},
         }
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would sit in the barrier)
             res["cpu_baseline"] = cpu_baseline(args.difficulty)
         if not args.no_extras and world == 1:
-            del b, out, a1_all
+            del b, out, a1_all, step
             torch.cuda.empty_cache()
             res["extras"] = side_measurements(torch, np, n)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

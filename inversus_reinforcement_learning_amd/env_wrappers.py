@@ -25,7 +25,7 @@ import torch
 
 from . import _lib as L
 from .device_env import DeviceEnvBatch
-from .vocab import Action, ActionType, Bullet, PlayerId, PlayerState, TileColor, DIR_BY_CODE, TYPE_BY_CODE
+from .vocab import Action, ActionType, Bullet, PlayerId, PlayerState, TileColor, CODE_BY_DIR, DIR_BY_CODE, TYPE_BY_CODE
 
 MAX_AMMO = 6
 
@@ -44,28 +44,192 @@ def _entropy_seed():
     return int.from_bytes(os.urandom(8), "little") >> 1
 
 
-class _CoreView:
-    """Read-only snapshot of one env's core state with the reference's field names
-    (InversusEnv: width, height, grid, player1, player2, bullets, get_player, ...)."""
+class _FrozenBullet(Bullet):
+    """A bullet handed out by `env.bullets`: a copy of device state.  Changing a field of the copy would not reach the
+    device, so it raises; assign a new list (`env.bullets = [...]`) instead, as the reference's tests do."""
+    __slots__ = ("_frozen",)
 
-    def __init__(self, batch, i, state):
+    def __init__(self, x, y, dir, owner):
+        Bullet.__init__(self, x, y, dir, owner)
+        object.__setattr__(self, "_frozen", True)
+
+    def __setattr__(self, name, value):
+        if getattr(self, "_frozen", False):
+            raise AttributeError("bullets read from the device are copies: assign env.bullets = [...] to change them")
+        object.__setattr__(self, name, value)
+
+    def __eq__(self, other):
+        return isinstance(other, Bullet) and (self.x, self.y, self.dir, self.owner) == (other.x, other.y, other.dir, other.owner)
+
+    __hash__ = None
+
+
+class _BulletList(list):
+    """`env.bullets`: a list whose mutations are written back to the device (append / extend / clear / pop / remove / insert /
+    item assignment / del / += / sort / reverse)."""
+
+    def __init__(self, view, items):
+        super().__init__(items)
+        self._view = view
+
+
+def _writes_back(name):
+    def method(self, *a, **k):
+        out = getattr(list, name)(self, *a, **k)
+        self._view.bullets = list(self)
+        return self if name == "__iadd__" else out
+    method.__name__ = name
+    return method
+
+
+for _m in ("append", "extend", "clear", "pop", "remove", "insert", "__setitem__", "__delitem__", "__iadd__", "sort", "reverse"):
+    setattr(_BulletList, _m, _writes_back(_m))
+
+
+class _PlayerView:
+    """`env.player1` / `env.player2`: the reference's PlayerState fields (game_types.py:52-62) LIVE on the device --
+    reads fetch the env's record, assignments (`env.player1.x = 3`, the idiom of every reference test) go through inv_set_state."""
+    _COL = {"x": 0, "y": 1, "ammo": 2, "reload_counter": 3, "alive": 4}
+
+    def __init__(self, view, q):
+        object.__setattr__(self, "_view", view)
+        object.__setattr__(self, "_q", q)
+
+    player_id = property(lambda self: PlayerId.P2 if self._q else PlayerId.P1)
+    color = property(lambda self: TileColor.WHITE if self._q else TileColor.BLACK)       # config.py:9,11; core.py:76,128
+    max_ammo = property(lambda self: MAX_AMMO)
+
+    def __getattr__(self, name):
+        col = _PlayerView._COL.get(name)
+        if col is None:
+            raise AttributeError(name)
+        v = int(self._view._field("players")[self._view._i, self._q, col])
+        return bool(v) if name == "alive" else v
+
+    def __setattr__(self, name, value):
+        col = _PlayerView._COL.get(name)
+        if col is None:
+            raise AttributeError(f"PlayerState.{name} is not settable on the device view")
+        v = int(bool(value)) if name == "alive" else int(value)
+        if not 0 <= v <= 255:
+            raise ValueError(f"{name}={value} does not fit the device record (0..255)")
+        pl = self._view._field("players")
+        pl[self._view._i, self._q, col] = v
+        self._view._batch.set_state(players=pl)
+
+    def __repr__(self):
+        return (f"PlayerState(player_id={self.player_id}, x={self.x}, y={self.y}, color={self.color}, ammo={self.ammo}, "
+                f"max_ammo={self.max_ammo}, reload_counter={self.reload_counter}, alive={self.alive})")
+
+
+class _GridRow:
+    def __init__(self, view, y):
+        self._view, self._y = view, y
+
+    def __len__(self):
+        return self._view.width
+
+    def __getitem__(self, x):
+        if isinstance(x, slice):
+            return [self[k] for k in range(*x.indices(self._view.width))]
+        return self._view._get_tile(x if x >= 0 else x + self._view.width, self._y)
+
+    def __setitem__(self, x, color):
+        self._view._set_tile(x if x >= 0 else x + self._view.width, self._y, color)
+
+    def __iter__(self):
+        return iter(self[:])
+
+    def count(self, color):
+        return self[:].count(color)
+
+    def __eq__(self, other):
+        return self[:] == list(other)
+
+
+class _GridView:
+    """`env.grid`: `env.grid[y][x]` reads and writes the device bitstring."""
+
+    def __init__(self, view):
+        self._view = view
+
+    def __len__(self):
+        return self._view.height
+
+    def __getitem__(self, y):
+        if isinstance(y, slice):
+            return [self[k] for k in range(*y.indices(self._view.height))]
+        if not -self._view.height <= y < self._view.height:
+            raise IndexError("list index out of range")
+        return _GridRow(self._view, y % self._view.height)
+
+    def __iter__(self):
+        return (self[y] for y in range(self._view.height))
+
+
+class _CoreView:
+    """`runner.envs[i].env`: env i's core state with the reference's field and method names (InversusEnv, core.py:17-544),
+    LIVE: attribute reads fetch from the device, attribute writes go through inv_set_state, and the core's own methods
+    (`update_bullets`, `step_players`, `try_move_player`, `spawn_bullet`, `spawn_wide_shot`, `_reload_ammo`, `step`) run the
+    corresponding phase of the step kernel on this env only (inv_step_masked with INV_PHASE_* flags), so the reference's
+    state-poking tests read the same here.  Every access synchronises: this is the debugging / test surface, not the hot path."""
+
+    def __init__(self, batch, i):
+        self._batch, self._i = batch, int(i)
         self.width, self.height = batch.W, batch.H
         self.player_color = TileColor.BLACK
-        W, H = batch.W, batch.H
-        words = state["grid"][i]
-        bits = ((words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[:W * H]
-        self.grid = [[TileColor.WHITE if bits[y * W + x] else TileColor.BLACK for x in range(W)] for y in range(H)]
-        pl = state["players"][i]
-        mk = lambda q, pid, col: PlayerState(pid, int(pl[q, 0]), int(pl[q, 1]), col, int(pl[q, 2]), MAX_AMMO,
-                                             int(pl[q, 3]), bool(pl[q, 4]))
-        self.player1 = mk(0, PlayerId.P1, TileColor.BLACK)
-        self.player2 = mk(1, PlayerId.P2, TileColor.WHITE)
-        self.bullets = []
-        for w in state["bullets"][i][:int(state["nbullets"][i])]:
-            w = int(w)
-            self.bullets.append(Bullet(w & 63, (w >> 6) & 63, DIR_BY_CODE[(w >> 12) & 3],
-                                       PlayerId.P2 if (w >> 14) & 1 else PlayerId.P1))
+        self.player1, self.player2 = _PlayerView(self, 0), _PlayerView(self, 1)
 
+    # ---- state plumbing
+    def _field(self, name):
+        return self._batch.get_state((name,))[name]
+
+    def __setattr__(self, name, value):
+        if name in ("player1", "player2") and name in self.__dict__:
+            raise AttributeError(f"assign the fields of env.{name} (x, y, ammo, reload_counter, alive), not the object")
+        if name == "grid":
+            rows = [list(r) for r in value]
+            if len(rows) != self.height or any(len(r) != self.width for r in rows):
+                raise ValueError("grid must be height x width")
+            g = self._field("grid")
+            g[self._i] = 0
+            for y, row in enumerate(rows):
+                for x, c in enumerate(row):
+                    if c == TileColor.WHITE:
+                        p = y * self.width + x
+                        g[self._i, p >> 5] |= np.uint32(1 << (p & 31))
+            self._batch.set_state(grid=g)
+            return
+        object.__setattr__(self, name, value)
+
+    @property
+    def grid(self):
+        return _GridView(self)
+
+    @property
+    def bullets(self):
+        st = self._batch.get_state(("bullets", "nbullets"))
+        out = []
+        for w in st["bullets"][self._i][:int(st["nbullets"][self._i])]:
+            w = int(w)
+            out.append(_FrozenBullet(w & 63, (w >> 6) & 63, DIR_BY_CODE[(w >> 12) & 3], PlayerId.P2 if (w >> 14) & 1 else PlayerId.P1))
+        return _BulletList(self, out)
+
+    @bullets.setter
+    def bullets(self, lst):
+        lst = list(lst)
+        if len(lst) > self._batch.K:
+            raise ValueError(f"more than max_bullets={self._batch.K} bullets")
+        st = self._batch.get_state(("bullets", "nbullets"))
+        st["bullets"][self._i] = 0
+        for k, b in enumerate(lst):
+            if not (0 <= int(b.x) < 64 and 0 <= int(b.y) < 64):
+                raise ValueError(f"bullet position ({b.x}, {b.y}) does not fit the device record")
+            st["bullets"][self._i, k] = int(b.x) | (int(b.y) << 6) | (CODE_BY_DIR[b.dir] << 12) | ((0 if b.owner == PlayerId.P1 else 1) << 14)
+        st["nbullets"][self._i] = len(lst)
+        self._batch.set_state(bullets=st["bullets"], nbullets=st["nbullets"])
+
+    # ---- reads (core.py:183-247, 477-495)
     def get_player(self, pid):
         if pid == PlayerId.P1:
             return self.player1
@@ -73,23 +237,115 @@ class _CoreView:
             return self.player2
         raise ValueError(f"Invalid player ID: {pid}")
 
+    def get_player_position(self, pid=None):
+        p = self.get_player(PlayerId.P1 if pid is None else pid)
+        return p.x, p.y
+
+    def is_player_alive(self, pid):
+        return self.get_player(pid).alive
+
     def get_bullets(self):
         return list(self.bullets)
 
     def get_grid_copy(self):
-        return [row[:] for row in self.grid]
+        words = self._field("grid")[self._i]
+        W, H = self.width, self.height
+        bits = ((words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[:W * H]
+        return [[TileColor.WHITE if bits[y * W + x] else TileColor.BLACK for x in range(W)] for y in range(H)]
+
+    def _tile_in_bounds(self, x, y):
+        return 0 <= x < self.width and 0 <= y < self.height
+
+    def _get_tile(self, x, y):
+        if not self._tile_in_bounds(x, y):
+            raise IndexError(f"Tile ({x}, {y}) out of bounds")              # core.py:229
+        p = y * self.width + x
+        return TileColor.WHITE if (int(self._field("grid")[self._i, p >> 5]) >> (p & 31)) & 1 else TileColor.BLACK
+
+    def _set_tile(self, x, y, color):
+        if not self._tile_in_bounds(x, y):
+            raise IndexError(f"Tile ({x}, {y}) out of bounds")              # core.py:235
+        g = self._field("grid")
+        p = y * self.width + x
+        if color == TileColor.WHITE:
+            g[self._i, p >> 5] |= np.uint32(1 << (p & 31))
+        else:
+            g[self._i, p >> 5] &= np.uint32(~(1 << (p & 31)) & 0xFFFFFFFF)
+        self._batch.set_state(grid=g)
+
+    def _is_walkable_for_player(self, x, y, player_color):
+        return self._tile_in_bounds(x, y) and self._get_tile(x, y) != player_color
 
     def is_round_over(self):
-        return not (self.player1.alive and self.player2.alive)
+        pl = self._field("players")[self._i]
+        return not (pl[0, 4] and pl[1, 4])
 
     def get_winner(self):
-        if not self.is_round_over():
-            return None
-        if not self.player1.alive and self.player2.alive:
-            return PlayerId.P2
-        if not self.player2.alive and self.player1.alive:
-            return PlayerId.P1
-        return None
+        pl = self._field("players")[self._i]
+        a1, a2 = bool(pl[0, 4]), bool(pl[1, 4])
+        if a1 == a2:
+            return None                                                      # still running, or a double KO (core.py:483-495)
+        return PlayerId.P1 if a1 else PlayerId.P2
+
+    # ---- the core's tick pieces, on this env only
+    def _phase(self, flags, a1=0, a2=0):
+        b = self._batch
+        act1 = np.zeros(b.num_envs, np.uint8)
+        act2 = np.zeros(b.num_envs, np.uint8)
+        mask = np.zeros(b.num_envs, np.uint8)
+        act1[self._i], act2[self._i], mask[self._i] = a1, a2, 1
+        b.step(act1, act2, flags=flags, obs=False, mask=mask)
+        b.check()
+
+    @staticmethod
+    def _action_id(action):
+        if action.type == ActionType.NONE or action.direction is None:
+            return 0
+        return {ActionType.MOVE: 1, ActionType.SHOOT: 5, ActionType.CHARGE_SHOOT: 9}[action.type] + CODE_BY_DIR[action.direction]
+
+    def _solo(self, pid, action_id):
+        pid = PlayerId.P1 if pid is None else pid
+        if pid not in (PlayerId.P1, PlayerId.P2):
+            raise ValueError(f"Invalid player ID: {pid}")
+        q = 0 if pid == PlayerId.P1 else 1
+        before = self._batch.get_state(("players",))["players"][self._i, q].copy()
+        self._phase(L.INV_PHASE_ACTIONS, action_id if q == 0 else 0, action_id if q == 1 else 0)
+        after = self._batch.get_state(("players",))["players"][self._i, q]
+        return before, after
+
+    def try_move_player(self, direction, pid=None):
+        before, after = self._solo(pid, 1 + CODE_BY_DIR[direction])
+        return bool(before[0] != after[0] or before[1] != after[1])          # core.py:249-296: True iff the player moved
+
+    def spawn_bullet(self, direction, pid=None):
+        before, after = self._solo(pid, 5 + CODE_BY_DIR[direction])
+        return bool(after[2] == before[2] - 1)                               # core.py:298-326: True iff a bullet was fired
+
+    def spawn_wide_shot(self, pid, direction):
+        before, after = self._solo(pid, 9 + CODE_BY_DIR[direction])
+        return bool(after[2] == before[2] - 3)                               # core.py:328-381
+
+    def _reload_ammo(self):
+        self._phase(L.INV_PHASE_RELOAD)
+
+    def update_bullets(self):
+        self._phase(L.INV_PHASE_BULLETS)
+
+    def step_players(self, action_p1, action_p2):
+        self._phase(L.INV_PHASE_ACTIONS | L.INV_PHASE_RELOAD | L.INV_PHASE_BULLETS, self._action_id(action_p1), self._action_id(action_p2))
+
+    def step(self, action):
+        self.step_players(action, Action(ActionType.NONE, None))
+
+    def reset(self, seed=None):
+        b = self._batch
+        mask = np.zeros(b.num_envs, np.uint8)
+        mask[self._i] = 1
+        if seed is not None:
+            seeds = np.zeros(b.num_envs, np.int64)
+            seeds[self._i] = int(seed)
+            b.seed(seeds, mask)
+        b.reset(mask)
 
 
 class _EnvHandle:
@@ -100,7 +356,7 @@ class _EnvHandle:
 
     @property
     def env(self):
-        return _CoreView(self._r.batch, self._i, self._r.batch.get_state())
+        return _CoreView(self._r.batch, self._i)
 
     @property
     def step_count(self):

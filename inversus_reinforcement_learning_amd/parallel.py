@@ -17,11 +17,22 @@ def world():
     return 0, 1
 
 
+def initialized():
+    """A process group exists (possibly of ONE rank: INVERSUS_FORCE_DIST=1 runs the collectives' code path -- communicator
+    creation, all-reduce launches -- on a single GPU, which is how the RCCL branch is exercised on a 1-GPU box)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun, or bench.py's own
+    child ranks).  INVERSUS_FORCE_DIST=1 initialises a group even for WORLD_SIZE=1."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or dist.is_initialized():
+    force = os.environ.get("INVERSUS_FORCE_DIST") == "1"
+    if (ws <= 1 and not force) or dist.is_initialized():
         return world()
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("MASTER_PORT", "29531")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
         # INVERSUS_DIST_BACKEND=gloo + INVERSUS_SHARE_DEVICE=1 rehearse the multi-rank path on a 1-GPU box
@@ -71,10 +82,18 @@ class FlatGradReducer:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
         self._pending, self._work = len(self.early), None
-        _, w = world()
-        if w > 1:
+        self._hooks = []
+        if initialized():
             for p in self.early:
-                p.register_post_accumulate_grad_hook(self._early_ready)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._early_ready))
+
+    def close(self):
+        """Remove the hooks and release the parameters' .grad aliases (an agent that drops its reducer must call this)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            p.grad = None
 
     def _early_ready(self, _param):
         self._pending -= 1
@@ -82,12 +101,24 @@ class FlatGradReducer:
             self._work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
 
     def zero(self):
+        """Zero the gradients.  Always use this instead of optimizer.zero_grad() / module.zero_grad(): those default to
+        set_to_none=True, which detaches the parameters' .grad from the bucket (reduce() repairs and reports that)."""
         self.flat.zero_()
         self._pending, self._work = len(self.early), None
 
+    def _check_aliases(self):
+        off = 0
+        for p in self.params:
+            want = self.flat[off:off + p.numel()]
+            if p.grad is None or p.grad.data_ptr() != want.data_ptr():
+                raise RuntimeError("FlatGradReducer: a parameter's .grad no longer aliases the flat bucket (zero_grad(set_to_none=True)?); "
+                                   "zero gradients with reducer.zero()")
+            off += p.numel()
+
     def reduce(self):
+        self._check_aliases()
         _, w = world()
-        if w > 1:
+        if initialized():
             if self._work is not None:                      # the heads' part is already travelling (or done)
                 self._work.wait()
                 if self.n_early < self.flat.numel():
@@ -116,3 +147,55 @@ def broadcast_parameters(module, src=0):
     if w > 1:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
+
+
+def gather_scalars(x, device=None):
+    """[x of rank 0, x of rank 1, ...] as a list of floats on every rank (one all-reduce of a one-hot vector: works on every backend)."""
+    r, w = world()
+    if not initialized():
+        return [float(x)]
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    v = torch.zeros(w, dtype=torch.float64, device=dev)
+    v[r] = float(x)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return [float(t) for t in v.tolist()]
+
+
+def parameter_digest(module):
+    """sum |p| over all parameters in f64: identical on every rank while the replicas are in sync (the all-reduced
+    gradient is bit-identical on all ranks, so are Adam's updates)."""
+    return float(sum(p.detach().double().abs().sum() for p in module.parameters()))
+
+
+def assert_replicas_in_sync(module):
+    """Cross-rank parameter-digest check: raises if any rank's parameters differ from rank 0's."""
+    d = parameter_digest(module)
+    if initialized():
+        all_d = gather_scalars(d, device=next(module.parameters()).device if dist.get_backend() == "nccl" else "cpu")
+        if any(x != all_d[0] for x in all_d):
+            raise RuntimeError(f"policy replicas diverged across ranks: parameter digests {all_d}")
+    return d
+
+
+def merge_episode_tails(tail, total, window=100, device="cpu"):
+    """Global last-`window` episodes (training.py:162-170 keeps ONE list in completion order: vector step, then env index).
+    tail: this rank's last <= window episodes as rows (key, return, length, win) with key = step_serial * 2^32 + global env
+    index; total: episodes this rank has finished so far.  Returns (rows [<= window, 4] sorted by key, global total).
+    One all-gather of window x 4 f64 per rank and one scalar sum -- the episode-stat reduce of SURVEY 8(e)."""
+    rows = torch.full((window, 4), -1.0, dtype=torch.float64)
+    if len(tail):
+        t = torch.as_tensor(tail, dtype=torch.float64).reshape(-1, 4)[-window:]
+        rows[:t.shape[0]] = t
+    if initialized():
+        _, w = world()
+        dev = device if dist.get_backend() == "nccl" else "cpu"
+        mine = rows.to(dev)
+        parts = [torch.empty_like(mine) for _ in range(w)]
+        dist.all_gather(parts, mine)
+        rows = torch.cat(parts).cpu()
+        cnt = torch.tensor([float(total)], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total = int(cnt.item())
+    rows = rows[rows[:, 0] >= 0]
+    rows = rows[torch.argsort(rows[:, 0])][-window:]
+    return rows, int(total)

@@ -34,10 +34,9 @@ class PPOAgent:
         self.entropy_coef, self.value_coef = entropy_coef, value_coef
         self.gae_layout, self.max_grad_norm = gae_layout, max_grad_norm
         self.optimizer = optim.Adam(self.policy.parameters(), lr=lr)
-        _, w = parallel.world()
         # heads first in the bucket: their gradients are ready before the trunk's backward starts (see FlatGradReducer)
         heads = [p for name, p in self.policy.named_parameters() if name.startswith("fc_")]
-        self.reducer = parallel.FlatGradReducer(self.policy.parameters(), early=heads) if w > 1 else None
+        self.reducer = parallel.FlatGradReducer(self.policy.parameters(), early=heads) if parallel.initialized() else None
         # fused_act: rollouts use the fused bf16 trunk kernel (csrc/inv_policy.hip) instead of the f32
         # module; log-probs / values stored in the buffer then come from bf16 operands (~1e-2 off the f32
         # recomputation in update(), i.e. the PPO ratio starts at 1 +- 1e-2).  Default off = reference numerics.

@@ -10,6 +10,7 @@ and the plain `state_dict` checkpoints (so the reference's play.py / visualize_t
 them).  Multi-GPU: launch with torchrun; each rank owns a contiguous env shard, gradients are
 averaged with one RCCL all-reduce per optimizer step (parallel.py).
 """
+import collections
 import csv
 import os
 import time
@@ -23,6 +24,8 @@ from .device_env import DeviceEnvBatch, unpack_obs
 from .policies import InversusCNNPolicy
 from .ppo_agent import PPOAgent
 
+EPISODE_WINDOW = 100            # training.py:164-170: rolling means over the last 100 episodes
+DIGEST_EVERY = 10               # cross-rank parameter-digest check every this many updates (and at the end)
 CSV_COLUMNS = ["step", "episode", "avg_reward", "win_rate", "avg_ep_len", "policy_loss", "value_loss", "entropy"]
 
 
@@ -61,7 +64,12 @@ class RolloutCollector:
         self.packed = bool(packed_obs)
         self.obs = batch.render(0, bits=self.packed)
         self.obs_p2 = batch.render(1, bits=self.packed) if self.selfplay else None
-        self.episodes = {"return": [], "length": [], "win": []}
+        # finished episodes: a bounded tail in completion order (vector step, then global env index -- the order of the
+        # reference's single list, training.py:139-147) and a running count; nothing grows with the run
+        self.tail = collections.deque(maxlen=EPISODE_WINDOW)      # rows (key, return, length, win)
+        self.episodes_finished = 0
+        self._serial = 0                                          # vector steps so far (the major part of the key)
+        self._pending = []                                        # per-step (done, episode_return, episode_steps, info_flags)
 
     @torch.no_grad()
     def _opponent_actions(self):
@@ -86,16 +94,37 @@ class RolloutCollector:
             self.obs = (r.obs, r.extra)
             if self.selfplay:
                 self.obs_p2 = (r.obs_p2, r.extra_p2)
-            self._track(r)
+            self._pending.append((r.done, r.episode_return, r.episode_steps, r.info_flags))
+        self._drain()
         return steps * b.num_envs
 
-    def _track(self, r):
-        done = r.done.bool()
-        if bool(done.any()):                                  # one small D2H per step, like the reference's info dicts
-            idx = done.nonzero().flatten()
-            self.episodes["return"] += r.episode_return[idx].tolist()
-            self.episodes["length"] += r.episode_steps[idx].tolist()
-            self.episodes["win"] += ((r.info_flags[idx] & L.INV_INFO_WIN) != 0).int().tolist()
+    def _drain(self):
+        """Episode statistics of the steps collected since the last call: ONE gather + device->host copy per rollout
+        (the per-step outputs are fresh tensors, so holding them costs nothing), not one synchronisation per vector step."""
+        if not self._pending:
+            return
+        done = torch.stack([p[0] for p in self._pending]).bool()                  # [T, N]
+        t_idx, e_idx = done.nonzero(as_tuple=True)                                # row-major: step, then env == completion order
+        T = len(self._pending)
+        if t_idx.numel():
+            ret = torch.stack([p[1] for p in self._pending])[t_idx, e_idx]
+            length = torch.stack([p[2] for p in self._pending])[t_idx, e_idx].double()
+            win = ((torch.stack([p[3] for p in self._pending])[t_idx, e_idx] & L.INV_INFO_WIN) != 0).double()
+            key = (self._serial + t_idx).double() * float(2 ** 32) + (e_idx + self.batch.env_offset).double()
+            rows = torch.stack([key, ret, length, win], dim=1)
+            self.episodes_finished += int(rows.shape[0])
+            self.tail.extend(rows[-EPISODE_WINDOW:].tolist())
+        self._serial += T
+        self._pending = []
+
+    def episode_stats(self):
+        """(global episode count, avg return, win rate, avg length) over the GLOBAL last-100 window (training.py:162-170),
+        identical on every rank; None while no episode has finished anywhere."""
+        rows, total = parallel.merge_episode_tails(list(self.tail), self.episodes_finished, EPISODE_WINDOW, self.batch.device)
+        if rows.shape[0] == 0:
+            return None
+        m = rows[:, 1:].mean(dim=0)
+        return total, float(m[0]), float(m[2]), float(m[1])
 
 
 def _make(num_envs_total, opponent_type, difficulty, seed, width, height):
@@ -139,37 +168,41 @@ def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, w
     logger = TrainingLogger(log_dir) if (log_dir and rank == 0) else None
 
     steps_per_env = max(2048 // num_envs, 128)                      # training.py:105-107
-    step_count, episode_count, last_log, last_refresh = 0, 0, 0, 0
+    step_count, episode_count, last_log, last_refresh, updates = 0, 0, 0, 0, 0
     stats, t0 = {}, time.time()
     while step_count < total_steps:
         todo = min(steps_per_env, -(-(total_steps - step_count) // num_envs))
         collector.collect(todo)
         step_count += todo * num_envs
         stats = agent.update()
+        updates += 1
+        if world_size > 1 and updates % DIGEST_EVERY == 0:
+            parallel.assert_replicas_in_sync(policy)
         if mode == "selfplay" and step_count - last_refresh >= 20000:   # training.py:265,331-334
             opp_module.load_state_dict(policy.state_dict())
             if opponent is not opp_module:
                 opponent.refresh()
             last_refresh = step_count
-        ep = collector.episodes
-        episode_count = len(ep["return"]) * world_size
-        if ep["return"] and (step_count - last_log >= 1000 or step_count >= total_steps):
-            last_log = step_count
-            row = dict(step=step_count, episode=episode_count, avg_reward=float(np.mean(ep["return"][-100:])),
-                       win_rate=float(np.mean(ep["win"][-100:])), avg_ep_len=float(np.mean(ep["length"][-100:])),
-                       policy_loss=stats.get("policy_loss", 0.0), value_loss=stats.get("value_loss", 0.0),
-                       entropy=stats.get("entropy", 0.0))
-            if logger:
-                logger.log(**row)
-            if verbose and rank == 0:
-                print(f"Step {step_count}/{total_steps} | Episodes: {episode_count} | Avg Reward: {row['avg_reward']:.3f} | "
-                      f"Win Rate: {row['win_rate']:.3f} | Avg Ep Len: {row['avg_ep_len']:.1f} | Time: {time.time() - t0:.1f}s")
+        if step_count - last_log >= 1000 or step_count >= total_steps:
+            # every rank takes part: the global last-100 window and the global episode count are collectives
+            es = collector.episode_stats()
+            if es is not None:                                           # training.py:163: nothing is logged before the first episode ends
+                last_log = step_count
+                episode_count = es[0]
+                row = dict(step=step_count, episode=episode_count, avg_reward=es[1], win_rate=es[2], avg_ep_len=es[3],
+                           policy_loss=stats.get("policy_loss", 0.0), value_loss=stats.get("value_loss", 0.0),
+                           entropy=stats.get("entropy", 0.0))
+                if logger:
+                    logger.log(**row)
+                if verbose and rank == 0:
+                    print(f"Step {step_count}/{total_steps} | Episodes: {episode_count} | Avg Reward: {row['avg_reward']:.3f} | "
+                          f"Win Rate: {row['win_rate']:.3f} | Avg Ep Len: {row['avg_ep_len']:.1f} | Time: {time.time() - t0:.1f}s")
         if log_dir and rank == 0 and step_count % 50000 == 0:
             torch.save(policy.state_dict(), os.path.join(log_dir, f"policy_checkpoint_{step_count}.pt"))
     batch.check()
     if log_dir and rank == 0:
         torch.save(policy.state_dict(), os.path.join(log_dir, "policy_final.pt"))
-    digest = float(sum(p.detach().double().abs().sum() for p in policy.parameters()))   # same on every rank if in sync
+    digest = parallel.assert_replicas_in_sync(policy)                                     # raises if the ranks diverged
     return {"steps": step_count, "episodes": episode_count, "seconds": time.time() - t0, "param_abs_sum": digest, **stats}
 
 

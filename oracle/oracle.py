@@ -271,17 +271,19 @@ class OracleBatch:
             self.L.orc_build_obs(self.L.orc_batch_at(self.envs, i), pid, _ptr(g[i]), _ptr(x[i]))
         return g, x
 
+    def alloc_out(self, want_obs=True):
+        """Output buffers for step(out=...): allocated once, untouched (the first step's writers fault the pages in)."""
+        n = self.n
+        return (np.empty((n, 12, self.H, self.W), dtype=np.float32) if want_obs else None,
+                np.empty((n, 4), dtype=np.float32) if want_obs else None,
+                np.empty(n, dtype=np.float32), np.empty(n, dtype=np.float64), np.empty(n, dtype=np.uint8), (OrcInfo * n)())
+
     def step(self, a1, a2=None, hard=False, opp_seed=0, env_offset=0, auto_reset=True,
-             want_obs=True, nthreads=1):
+             want_obs=True, nthreads=1, out=None):
         n = self.n
         a1 = np.ascontiguousarray(a1, dtype=np.uint8)
         a2c = None if a2 is None else np.ascontiguousarray(a2, dtype=np.uint8)
-        obs = np.empty((n, 12, self.H, self.W), dtype=np.float32) if want_obs else None
-        extra = np.empty((n, 4), dtype=np.float32) if want_obs else None
-        reward = np.empty(n, dtype=np.float32)
-        reward64 = np.empty(n, dtype=np.float64)
-        done = np.empty(n, dtype=np.uint8)
-        info = (OrcInfo * n)()
+        obs, extra, reward, reward64, done, info = out if out is not None else self.alloc_out(want_obs)
         self.L.orc_batch_step(self.envs, n, _ptr(a1), _ptr(a2c), int(hard), opp_seed, env_offset,
                               int(auto_reset), _ptr(obs), _ptr(extra), _ptr(reward), _ptr(reward64),
                               _ptr(done), C.cast(info, C.c_void_p), nthreads)

@@ -85,7 +85,8 @@ def main():
     pol_s.load_state_dict(ref_state)
     agent_s = PPOAgent(pol_s, **kw)
     agent_s.optimizer = torch.optim.SGD(pol_s.parameters(), lr=0.05)
-    agent_s.reducer = None                         # single-process reference on the whole rollout
+    agent_s.reducer.close()                        # single-process reference on the whole rollout: no hooks, no bucket
+    agent_s.reducer = None
     # PPOAgent normalises with the all-rank statistics; feed it pre-normalised-equivalent data by running on all columns:
     # with world == 2 global_mean_std all-reduces, so give each rank the full data scaled to keep the sums equal
     grid, extra, actions, logp, values, rewards, dones, adv, ret = data
@@ -96,6 +97,38 @@ def main():
     flat_s = torch.cat([p.detach().reshape(-1) for p in pol_s.parameters()])
     err = float((flat - flat_s).abs().max())
     assert err < 5e-6, f"distributed step differs from the single-process step: {err}"
+    # episode statistics: the global last-100 window in completion order (vector step, then global env index) and the
+    # global count, from per-rank tails (training.py:162-170 keeps ONE list; SURVEY 8e "episode-stat reduce")
+    rng = np.random.RandomState(3)
+    n_ep = 260
+    steps = np.sort(rng.randint(0, 40, n_ep))
+    envs = rng.randint(0, 8, n_ep)
+    keys = steps.astype(np.float64) * 2.0 ** 32 + envs
+    rows = np.stack([keys, rng.randn(n_ep), rng.randint(1, 500, n_ep).astype(np.float64), rng.randint(0, 2, n_ep).astype(np.float64)], 1)
+    rows = rows[np.unique(keys, return_index=True)[1]]                     # one episode per (step, env)
+    mine = rows[(rows[:, 0] % 2 ** 32 >= off) & (rows[:, 0] % 2 ** 32 < off + cnt)]
+    merged, total = parallel.merge_episode_tails(mine[-100:].tolist(), len(mine), 100)
+    assert total == len(rows), (total, len(rows))
+    assert np.array_equal(merged.numpy(), rows[-100:]), "global last-100 window differs from the single-list window"
+
+    # gradient bucket hygiene: zero_grad(set_to_none=True) detaches .grad from the bucket -> reduce() must refuse
+    agent_d.optimizer.zero_grad()
+    try:
+        agent_d.reducer.reduce()
+        raise SystemExit("reduce() accepted detached gradients")
+    except RuntimeError:
+        pass
+    digests = parallel.gather_scalars(parallel.parameter_digest(pol_d))
+    assert len(digests) == 2 and digests[0] == digests[1]
+    parallel.assert_replicas_in_sync(pol_d)
+    with torch.no_grad():
+        if rank == 1:
+            next(pol_d.parameters()).add_(1e-3)                            # a diverged replica must be caught on every rank
+    try:
+        parallel.assert_replicas_in_sync(pol_d)
+        raise SystemExit("diverged replicas not detected")
+    except RuntimeError:
+        pass
     dist.barrier()
     print("DIST_OK", rank, err)
     dist.destroy_process_group()

@@ -1,0 +1,94 @@
+"""bench.py's N > 1 entry points: `python bench.py --gpus N` must start its own fresh child ranks when no
+launcher did, keep working under an external launcher, run the RCCL ("nccl") branch, and print ONE JSON line from rank 0
+with `n_gpus = N` and a per-rank k_step time list."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAUNCHER_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "INVERSUS_FORCE_DIST")
+
+
+def run_bench(*flags, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, cwd=ROOT, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def parse_line(proc):
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]                       # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_self_launch_fails_cleanly_without_gpus():
+    """CPU: the parent spawns 2 child ranks (no GPU call in the parent); without GPUs each child exits with a message, the
+    parent reaps both and returns non-zero instead of hanging in a rendezvous."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without GPUs")
+    p = run_bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-extras", timeout=180)
+    assert p.returncode != 0 and "has no GPU" in p.stderr and p.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_self_launched_two_ranks_share_the_gpu_over_gloo():
+    """`python bench.py --gpus 2` WITHOUT torchrun: two fresh child ranks (sharing the one GPU of the box over gloo)."""
+    res = parse_line(run_bench("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "50", "--warmup", "5",
+                               "--repeats", "3", "--no-cpu-baseline", "--no-extras"))
+    assert res["n_gpus"] == 2 and res["steps"] == 50 and res["scaling"] == "weak" and res["repeats"] == 3
+    assert len(res["roofline"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in res["roofline"]["kernel_ms_per_rank"])
+    assert abs(res["value"] - 2 * 16384 * 50 / (res["ms_per_step"] * 50e-3)) < 1e-3 * res["value"]
+    assert len(res["ms_per_step_repeats"]) == 3 and sorted(res["ms_per_step_repeats"])[1] == pytest.approx(res["ms_per_step"], rel=1e-4)
+
+
+@pytest.mark.gpu
+def test_external_launcher_is_respected():
+    """Under torch.distributed.run (the driver's N > 1 form) bench.py must NOT spawn again."""
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+                        "--steps", "30", "--warmup", "5", "--repeats", "1", "--no-cpu-baseline", "--no-extras"],
+                       env=env, cwd=ROOT, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    res = parse_line(p)
+    assert res["n_gpus"] == 2 and len(res["roofline"]["kernel_ms_per_rank"]) == 2
+
+
+@pytest.mark.gpu
+def test_rccl_branch_runs_with_one_rank():
+    """The nccl (= RCCL) branch -- communicator creation on the GPU, barrier, MAX / SUM all-reduces of the timing -- executed
+    for real on the 1-GPU box with a one-rank group (--force-dist)."""
+    res = parse_line(run_bench("--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "50", "--warmup", "5", "--repeats", "2",
+                               "--no-cpu-baseline", "--no-extras"))
+    assert res["n_gpus"] == 1 and res["config"]["backend"] == "nccl" and len(res["roofline"]["kernel_ms_per_rank"]) == 1
+
+
+@pytest.mark.gpu
+def test_rccl_two_ranks_when_two_gpus_are_visible():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node)")
+    res = parse_line(run_bench("--gpus", "2", "--steps", "50", "--warmup", "5", "--repeats", "2", "--no-cpu-baseline", "--no-extras"))
+    assert res["n_gpus"] == 2 and res["config"]["backend"] == "nccl"
+
+
+@pytest.mark.gpu
+def test_training_loop_over_rccl_with_one_rank():
+    """training.py's collectives (parameter broadcast, flat gradient all-reduce launched from the backward hooks, advantage
+    statistics, episode-stat all-gather, parameter-digest check) through RCCL on a one-rank group."""
+    code = ("import os; os.environ['INVERSUS_FORCE_DIST']='1'; os.environ['MASTER_PORT']='29579'\n"
+            "from inversus_reinforcement_learning_amd import training, parallel\n"
+            "import torch.distributed as dist\n"
+            "r = training.train_selfplay(num_envs=64, total_steps=64*128, log_dir=None, seed=2, verbose=False, agent_kwargs=dict(batch_size=1024, epochs=1))\n"
+            "assert dist.is_initialized() and dist.get_backend() == 'nccl', dist.get_backend()\n"
+            "print('RCCL_TRAIN_OK', r['steps'], r['episodes'], r['param_abs_sum'])\n"
+            "dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    env["PYTHONPATH"] = ROOT
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and "RCCL_TRAIN_OK 8192" in p.stdout, p.stdout[-3000:]

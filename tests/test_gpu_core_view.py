@@ -1,0 +1,132 @@
+"""`runner.envs[i].env` is LIVE: the state-poking idioms of the reference's test-suite (`env.player1.x = 3`,
+`env.bullets = [Bullet(...)]`, `env._set_tile(...)`, `env.update_bullets()`; tests/test_bullet_collision.py,
+test_combat_and_ammo.py, test_charge_shot.py, test_core_basic.py of the reference) work on the device env as written --
+assignments go through inv_set_state, the core's methods run the matching phase of the step kernel on that env only."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make(width=7, height=3, n=3, i=1):
+    from inversus_reinforcement_learning_amd.env_wrappers import MultiEnvRunner
+    runner = MultiEnvRunner(n, opponent_type="selfplay", seed=0, width=width, height=height)
+    return runner, runner.envs[i].env
+
+
+def test_assignments_reach_the_device_and_only_this_env():
+    from inversus_reinforcement_learning_amd.vocab import Bullet, Direction, PlayerId, TileColor
+    runner, env = make(15, 10)
+    before = runner.batch.get_state()
+    env.player1.x, env.player1.y = 3, 4
+    env.player2.ammo = 2
+    env.player2.alive = False
+    env._set_tile(9, 9, TileColor.WHITE)
+    env.grid[0][14] = TileColor.WHITE
+    env.bullets = [Bullet(x=5, y=5, dir=Direction.UP, owner=PlayerId.P2)]
+    after = runner.batch.get_state()
+    assert after["players"][1].tolist() == [[3, 4, before["players"][1, 0, 2], before["players"][1, 0, 3], 1],
+                                            [before["players"][1, 1, 0], before["players"][1, 1, 1], 2, before["players"][1, 1, 3], 0]]
+    assert env._get_tile(9, 9) == TileColor.WHITE and env.grid[0][14] == TileColor.WHITE and env.get_grid_copy()[9][9] == TileColor.WHITE
+    assert (env.player1.x, env.player1.y, env.player2.ammo, env.player2.alive) == (3, 4, 2, False)
+    assert env.bullets == [Bullet(5, 5, Direction.UP, PlayerId.P2)] and after["nbullets"][1] == 1
+    for k in (0, 2):                                                    # the neighbours are untouched
+        for f in ("players", "grid", "bullets", "nbullets"):
+            assert np.array_equal(before[f][k], after[f][k]), (k, f)
+    # fresh handles see the same device state (nothing is cached in the view)
+    assert runner.envs[1].env.player1.x == 3
+    with pytest.raises(IndexError):
+        env._set_tile(15, 0, TileColor.WHITE)                           # core.py:235
+
+
+def test_writes_that_cannot_reach_the_device_raise():
+    from inversus_reinforcement_learning_amd.vocab import Bullet, Direction, PlayerId, PlayerState, TileColor
+    runner, env = make()
+    env.bullets = [Bullet(1, 1, Direction.RIGHT, PlayerId.P1)]
+    with pytest.raises(AttributeError):
+        env.bullets[0].x = 4                                            # a copy: must not be silently ignored
+    with pytest.raises(AttributeError):
+        env.player1 = PlayerState(PlayerId.P1, 1, 1, TileColor.BLACK, 6, 6, 0, True)
+    with pytest.raises(AttributeError):
+        env.player1.color = TileColor.WHITE
+    lst = env.bullets
+    lst.append(Bullet(2, 1, Direction.LEFT, PlayerId.P2))               # list mutations write back
+    assert len(env.bullets) == 2 and env.bullets[1].owner == PlayerId.P2
+    env.bullets.clear()
+    assert env.bullets == []
+    with pytest.raises(ValueError):
+        env.bullets = [Bullet(0, 0, Direction.UP, PlayerId.P1)] * 17    # max_bullets = 16
+
+
+def test_bullet_collision_idiom():
+    """tests/test_bullet_collision.py of the reference, on a 7 x 3 board at y = 1: opposing bullets meeting on one tile
+    vanish without flipping it or hitting anyone; same-owner bullets do not cancel."""
+    from inversus_reinforcement_learning_amd.vocab import Bullet, Direction, PlayerId, TileColor
+    runner, env = make()
+    env.player1.x, env.player1.y, env.player2.x, env.player2.y = 0, 0, 6, 2
+    for x in range(7):
+        env._set_tile(x, 1, TileColor.BLACK)
+    env.bullets = [Bullet(x=1, y=1, dir=Direction.RIGHT, owner=PlayerId.P1), Bullet(x=3, y=1, dir=Direction.LEFT, owner=PlayerId.P2)]
+    env.update_bullets()
+    assert len(env.bullets) == 0
+    assert env._get_tile(2, 1) == TileColor.BLACK                        # no flip at the collision tile
+    assert env.player1.alive and env.player2.alive
+    env.bullets = [Bullet(x=1, y=1, dir=Direction.RIGHT, owner=PlayerId.P1), Bullet(x=3, y=1, dir=Direction.LEFT, owner=PlayerId.P1)]
+    env.update_bullets()
+    assert len(env.bullets) == 1 and env.bullets[0].dir == Direction.RIGHT   # merged into the first arrival (core.py:453)
+    assert env._get_tile(2, 1) == TileColor.WHITE                        # P1's bullet flips BLACK -> WHITE
+
+
+def test_ammo_reload_kill_and_winner_idioms():
+    """tests/test_combat_and_ammo.py of the reference: ammo consumption, empty magazine, 30-tick reload, kill + winner."""
+    from inversus_reinforcement_learning_amd.vocab import Action, ActionType, Bullet, Direction, PlayerId
+    runner, env = make(15, 10)
+    env.player1.x, env.player1.y, env.player2.x, env.player2.y = 2, 5, 12, 5
+    env.bullets = []
+    env.player1.ammo = 1
+    assert env.spawn_bullet(Direction.RIGHT, PlayerId.P1) is True and env.player1.ammo == 0 and len(env.bullets) == 1
+    assert env.spawn_bullet(Direction.RIGHT) is False and len(env.bullets) == 1      # empty magazine (core.py:313-315)
+    env.player1.ammo, env.player1.reload_counter = 5, 0
+    for _ in range(29):
+        env._reload_ammo()
+    assert env.player1.ammo == 5 and env.player1.reload_counter == 29
+    env._reload_ammo()
+    assert env.player1.ammo == 6 and env.player1.reload_counter == 0
+    env.bullets = [Bullet(x=11, y=5, dir=Direction.RIGHT, owner=PlayerId.P1)]
+    assert not env.is_round_over() and env.get_winner() is None
+    env.update_bullets()
+    assert not env.player2.alive and env.is_round_over() and env.get_winner() == PlayerId.P1
+    # dead players cannot act (core.py:519); step() is the single-player wrapper (core.py:533-544)
+    env.player2.ammo = 6
+    assert env.spawn_bullet(Direction.LEFT, PlayerId.P2) is False
+    x0 = env.player1.x
+    env._set_tile(x0 + 1, 5, env.player2.color)                          # WHITE: walkable for P1
+    env.step(Action(ActionType.MOVE, Direction.RIGHT))
+    assert env.player1.x == x0 + 1
+    assert env.try_move_player(Direction.UP, PlayerId.P1) in (True, False)
+    with pytest.raises(ValueError):
+        env.get_player(3)                                                # core.py:198
+
+
+def test_wide_shot_idiom():
+    """tests/test_charge_shot.py of the reference: three lanes, ammo cost 3, clipped at the edge, refused below 3 ammo."""
+    from inversus_reinforcement_learning_amd.vocab import Direction, PlayerId
+    runner, env = make(15, 10)
+    env.bullets = []
+    env.player1.x, env.player1.y, env.player1.ammo = 3, 5, 6
+    assert env.spawn_wide_shot(PlayerId.P1, Direction.UP) is True
+    assert sorted(b.x for b in env.bullets) == [2, 3, 4] and all(b.y == 5 and b.dir == Direction.UP for b in env.bullets)
+    assert env.player1.ammo == 3
+    env.bullets = []
+    env.player1.x, env.player1.y = 0, 0
+    assert env.spawn_wide_shot(PlayerId.P1, Direction.DOWN) is True and len(env.bullets) == 2 and env.player1.ammo == 0
+    assert env.spawn_wide_shot(PlayerId.P1, Direction.DOWN) is False
+
+
+def test_reset_through_the_view_continues_the_env_stream():
+    runner, env = make(15, 10)
+    from oracle import oracle as orc
+    o = orc.OracleEnv(15, 10, seed=1)                                    # env 1 of seed base 0
+    o.reset()                                                            # the runner's constructor reset + this one
+    env.reset()
+    assert (env.player1.x, env.player1.y, env.player2.x, env.player2.y) == tuple(o.players()[:, :2].reshape(-1))

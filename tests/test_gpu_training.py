@@ -42,7 +42,7 @@ def test_collector_transitions_match_oracle_replay():
         nxt = agent.obs_grid_buffer[t + 1] if t + 1 < T else col.obs[0]
         assert bits_eq(nxt.cpu().numpy(), o_obs), t
         ndone += int(o_done.sum())
-    assert ndone > 0 and len(col.episodes["return"]) == ndone
+    assert ndone > 0 and col.episodes_finished == ndone and len(col.tail) == min(ndone, 100)
     # GAE of the agent == oracle GAE on the same buffers, both layouts
     r = torch.stack(agent.reward_buffer).cpu().numpy(); v = torch.stack(agent.value_buffer).cpu().numpy()
     d = torch.stack(agent.done_buffer).cpu().numpy()
