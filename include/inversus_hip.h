@@ -16,6 +16,11 @@
  *   - every data pointer is a DEVICE pointer unless the parameter says `_host`.
  *   - all launches are asynchronous on `stream`; nothing synchronises except
  *     inv_check() and the `_host` copies.
+ *   - the uint8 inputs of inv_step / inv_step_masked / inv_rollout (a1, a2, mask) are read as
+ *     aligned 32-bit words through the scalar cache: the ALLOCATION behind each of them must
+ *     extend to the next 4-byte boundary past its last byte (hipMalloc and torch allocations
+ *     always do; a hand-carved sub-buffer at the very end of an allocation of odd size must be
+ *     padded).  The extra bytes are never interpreted.
  *   - return value: INV_OK or a negative inv_status; inv_last_error() gives text.
  *   - env i of a handle has GLOBAL index env_offset + i (multi-GPU sharding: one
  *     handle per rank over a contiguous global range; results do not depend on

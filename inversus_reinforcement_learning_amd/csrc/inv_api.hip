@@ -3,6 +3,7 @@
 // gfx950 only.  One wavefront per env (see inv_device.h); 4 envs per 256-thread block, no
 // workgroup barriers.  Every entry point is asynchronous on the caller's stream.
 #include "inv_device.h"
+#include "inv_internal.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -387,13 +388,24 @@ struct inv_handle {
 
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int inv_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
+}
+#define fail inv_fail
+
+int inv_cu_count()
+{
+    static int cus[64] = { 0 };                      // per device ordinal; 0 = not queried yet
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0)
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    return cus[dev];
 }
 
 #define HIP_TRY(expr)                                                                              \
@@ -429,8 +441,18 @@ int inv_create(const inv_config *cfg, inv_handle **out)
     if (cfg->opponent != INV_OPP_EXTERNAL && cfg->opponent != INV_OPP_DUMMY) return fail(INV_ERR_BAD_ARG, "Unknown opponent_type: %d", cfg->opponent);
 
     HIP_TRY(hipSetDevice(cfg->device));
-    inv_handle *h = new (std::nothrow) inv_handle();
+    inv_handle *h = new (std::nothrow) inv_handle();        // value-initialised: every pointer starts NULL
     if (!h) return fail(INV_ERR_BAD_ARG, "inv_create: out of host memory");
+    // from here on a failing HIP call releases whatever was allocated so far (inv_destroy accepts a partial handle)
+#undef HIP_TRY
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)inv_destroy(h);                                                                  \
+            return fail(INV_ERR_HIP, "inv_create: %s: %s", #expr, hipGetErrorString(e_));          \
+        }                                                                                          \
+    } while (0)
     h->cfg = *cfg;
     Dims &d = h->d;
     d.N = cfg->num_envs; d.W = cfg->width; d.H = cfg->height; d.WH = d.W * d.H; d.K = cfg->max_bullets;
@@ -467,14 +489,21 @@ int inv_create(const inv_config *cfg, inv_handle **out)
     HIP_TRY(hipDeviceSynchronize());
     *out = h;
     return INV_OK;
+#undef HIP_TRY
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(INV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
 }
 
 int inv_destroy(inv_handle *h)
 {
     if (!h) return INV_OK;
     void *dev[] = { h->s.head, h->s.grid, h->s.bullets, h->s.mt, h->s.err, h->prox, h->keys };
-    for (void *p : dev) (void)hipFree(p);
-    (void)hipHostFree(h->keys_host);
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    if (h->keys_host) (void)hipHostFree(h->keys_host);
     delete h;
     return INV_OK;
 }

@@ -111,6 +111,9 @@ __device__ __forceinline__ void wave_sync()
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
 typedef const __attribute__((address_space(4))) double *const_f64_ptr;
 
+// The byte is fetched as the ALIGNED 32-bit word that holds it, so up to 3 bytes beyond a buffer whose end is not 4-byte
+// aligned are read (never used).  They are inside the allocation for every allocator this library is fed from (hipMalloc
+// and torch round sizes up to >= 256 B); include/inversus_hip.h states the requirement for other callers.
 __device__ __forceinline__ uint32_t sload_u8(const uint8_t *p, size_t idx)
 {
     const uintptr_t a = (uintptr_t)p + idx;

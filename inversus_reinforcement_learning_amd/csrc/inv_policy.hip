@@ -29,6 +29,7 @@
 #include <string.h>
 
 #include "../../include/inversus_hip.h"
+#include "inv_internal.h"
 
 // bf16 pipeline, not bit-comparable with the f32 module anyway: let the epilogue use FMAs even though the
 // library is built with -ffp-contract=off for the env / GAE kernels
@@ -800,13 +801,14 @@ extern "C" int inv_policy_debug_stamps(unsigned long long *out16_host, int reset
 
 static int trunk_grid(int N)
 {
-    static int cus = 0;                              // CU count, queried once (not in a captured region)
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
+    const int cus = inv_cu_count();                  // of the current device (cached per device)
     return N < 2 * cus ? N : 2 * cus;               // two resident 256-thread workgroups per CU (55 KB of LDS each), persistent over samples
+}
+
+static int launch_status(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? INV_OK : inv_fail(INV_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
 static bool layers_ok(const inv_policy_params *params)
@@ -818,7 +820,8 @@ static bool layers_ok(const inv_policy_params *params)
 
 static int launch_trunk(const inv_policy_params *params, const void *obs, bool bits, void *feat_bf16, int32_t N, void *stream)
 {
-    if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params)) return INV_ERR_BAD_ARG;
+    if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params))
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk: NULL params / obs / feat, a NULL layer tensor, or N < 0");
     if (N == 0) return INV_OK;
     const int grid = trunk_grid(N);
     inv_policy_saved none;
@@ -829,7 +832,7 @@ static int launch_trunk(const inv_policy_params *params, const void *obs, bool b
     else
         hipLaunchKernelGGL((pol::k_policy_trunk<false, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
                            reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, none);
-    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+    return launch_status("inv_policy_trunk");
 }
 
 extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *obs, void *feat_bf16, int32_t N, void *stream)
@@ -853,7 +856,8 @@ static bool saved_ok(const inv_policy_saved *sv)
 extern "C" int inv_policy_trunk_train_fwd(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, void *feat_bf16,
                                           const inv_policy_saved *saved, int32_t N, void *stream)
 {
-    if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params) || (saved && !saved_ok(saved))) return INV_ERR_BAD_ARG;
+    if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params) || (saved && !saved_ok(saved)))
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_train_fwd: NULL params / obs / feat, a NULL layer or saved tensor, or N < 0");
     if (N == 0) return INV_OK;
     const int grid = trunk_grid(N);
     inv_policy_saved sv;
@@ -865,19 +869,21 @@ extern "C" int inv_policy_trunk_train_fwd(const inv_policy_params *params, const
     else
         hipLaunchKernelGGL((pol::k_policy_trunk<false, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
                            reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, sv);
-    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+    return launch_status("inv_policy_trunk_train_fwd");
 }
 
 extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const inv_policy_saved *saved, const void *dfeat_bf16,
                                     const inv_policy_grads *grads, int32_t N, void *stream)
 {
-    if (!params || !dfeat_bf16 || !grads || N < 0 || !saved_ok(saved)) return INV_ERR_BAD_ARG;
+    if (!params || !dfeat_bf16 || !grads || N < 0 || !saved_ok(saved))
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_bwd: NULL params / dfeat / grads, an incomplete saved set, or N < 0");
     for (int l = 0; l < 4; ++l)
-        if (!params->ln[l] || !grads->dy[l] || !grads->dz[l] || (l < 3 && !params->wt[l])) return INV_ERR_BAD_ARG;
+        if (!params->ln[l] || !grads->dy[l] || !grads->dz[l] || (l < 3 && !params->wt[l]))
+            return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_bwd: NULL tensor for layer %d", l);
     if (N == 0) return INV_OK;
     hipLaunchKernelGGL(pol::k_policy_trunk_bwd, dim3(trunk_grid(N)), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, *saved,
                        reinterpret_cast<const pol::bf16 *>(dfeat_bf16), *grads, (int)N);
-    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+    return launch_status("inv_policy_trunk_bwd");
 }
 
 template <int CINP, int COUT, int MWW, int NBW, bool PF>
@@ -886,23 +892,27 @@ static int launch_wgrad(const void *x, const void *dz, float *dw, float *db, int
     constexpr int MS = MWW * (pol::WG_WAVES / NBW), Q = (COUT / 16 + MS - 1) / MS;
     constexpr int DSTRIDE = MS * 16 + 8, XSTRIDE = CINP + 8;
     constexpr size_t lds = (size_t)(pol::KPAD * DSTRIDE + pol::NPOS * XSTRIDE) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return INV_ERR_HIP;
-        attr_set = true;
+    static bool attr_set[64] = { false };            // per device ordinal: the attribute belongs to the device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "inv_policy_wgrad: hipFuncSetAttribute(%d B of LDS): %s", (int)lds, hipGetErrorString(e));
+        attr_set[dev] = true;
     }
     const int blocks = PF ? trunk_grid(N) / 2 : trunk_grid(N);          // PF: one 8-wave block per CU; else two (<= 126 VGPRs, <= 68 KB LDS)
     const int per_slice = blocks / Q > 0 ? blocks / Q : 1;
     const int nslices = N < per_slice ? N : per_slice;
     hipLaunchKernelGGL((pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF>), dim3(nslices * Q), dim3(pol::WG_THREADS), lds, st,
                        reinterpret_cast<const pol::bf16 *>(x), reinterpret_cast<const pol::bf16 *>(dz), dw, db, N);
-    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+    return launch_status("inv_policy_wgrad");
 }
 
 extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, float *dbias, int32_t N, void *stream)
 {
-    if (!x_bf16 || !dz_bf16 || !dw || N < 0 || layer < 0 || layer > 3) return INV_ERR_BAD_ARG;
+    if (!x_bf16 || !dz_bf16 || !dw || N < 0 || layer < 0 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_wgrad: NULL x / dz / dw, N < 0 or layer outside 0..3 (dbias may be NULL)");
     if (N == 0) return INV_OK;
     hipStream_t st = (hipStream_t)stream;
     switch (layer) {
@@ -916,9 +926,10 @@ extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *d
 extern "C" int inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, float *partial, int32_t slices,
                                       int32_t elems_per_sample, int32_t N, void *stream)
 {
-    if (!dy_bf16 || !xhat_bf16 || !partial || N < 0 || slices < 1 || elems_per_sample <= 0 || (elems_per_sample & 7)) return INV_ERR_BAD_ARG;
+    if (!dy_bf16 || !xhat_bf16 || !partial || N < 0 || slices < 1 || elems_per_sample <= 0 || (elems_per_sample & 7))
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_param_grads: NULL tensor, N < 0, slices < 1 or elems_per_sample not a positive multiple of 8");
     const int e8 = elems_per_sample / 8, bx = (e8 + 255) / 256;
     hipLaunchKernelGGL(pol::k_policy_param_grads, dim3(bx, slices), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const pol::bf16 *>(dy_bf16),
                        reinterpret_cast<const pol::bf16 *>(xhat_bf16), partial, e8, (int)N);
-    return hipGetLastError() == hipSuccess ? INV_OK : INV_ERR_HIP;
+    return launch_status("inv_policy_param_grads");
 }

@@ -52,8 +52,11 @@ class RolloutCollector:
                a1 / a2 come from one batched forward of `policy` / `opponent` each (the reference
                does N batch-of-1 forwards, training.py:249-258)."""
 
-    def __init__(self, batch, agent, opponent=None, packed_obs=None):
+    def __init__(self, batch, agent, opponent=None, packed_obs=None, record_opponent_actions=False):
         self.batch, self.agent, self.opponent = batch, agent, opponent
+        # record_opponent_actions: keep the a2 of every vector step (device tensors) so a rollout can be replayed elsewhere
+        # (the parity tests replay sampled env columns through the oracle); off by default
+        self.opponent_actions = [] if record_opponent_actions else None
         self.selfplay = batch.opponent == "selfplay"
         if self.selfplay and opponent is None:
             raise ValueError("opponent_policy required for selfplay mode")
@@ -87,6 +90,8 @@ class RolloutCollector:
             grid, extra = self.obs
             actions, log_probs, values = agent.act(grid, extra)
             a2 = self._opponent_actions() if self.selfplay else None
+            if self.opponent_actions is not None and a2 is not None:
+                self.opponent_actions.append(a2)
             # fresh obs buffers per step: the rollout buffer keeps references to them (ppo_agent.py:119)
             out = b._alloc_out((), True, self.selfplay, False, None, self.packed)
             r = b.step(actions.to(torch.uint8), a2, auto_reset=True, out=out)

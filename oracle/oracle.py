@@ -63,8 +63,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    build()
-    L = C.CDLL(_LIB_PATH)
+    override = os.environ.get("INVERSUS_ORACLE_LIB")     # another build of the same source (the sanitizer build of the tests)
+    if not override:
+        build()
+    L = C.CDLL(override or _LIB_PATH)
     P = C.POINTER
     env_p = P(OrcEnv)
     sig = {
