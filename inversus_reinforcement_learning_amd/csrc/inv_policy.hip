@@ -44,6 +44,17 @@ constexpr int CSTRIDE = 136;                             // bf16 per position: 1
 constexpr int THREADS = 256, WAVES = THREADS / 64;       // 4 waves per block, 2 blocks per CU (55 KB LDS each)
 constexpr float LN_EPS = 1e-5f;
 
+// The GEMM loops below are software pipelines written out in source order (weight fragments requested AD k-steps ahead,
+// every activation fragment re-loaded right after its last MFMA of the k-step).  hipcc's scheduler undoes that: it sinks
+// the loads to just before their first use (ds_read_b128 ... s_waitcnt lgkmcnt ... v_mfma on the same registers; weight
+// loads waited on two instructions after their issue), which leaves every wave latency-bound and the matrix pipe busy only
+// when a co-resident wave happens to fill the gaps.  A scheduling barrier after each group pins the written order.
+#ifndef POL_NO_PIN
+#define POL_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define POL_PIN() do { } while (0)
+#endif
+
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -55,7 +66,7 @@ __device__ __forceinline__ int pos_of(int p) { return (p / W + 1) * PW + (p % W)
 // Diagnostic build only (-DINV_POLICY_STAMPS, never the shipped library): per-phase cycle shares of wave 0,
 // accumulated into a buffer of its own that no kernel code reads (cdna_hip_programming.md, "In-kernel stamps").
 #ifdef INV_POLICY_STAMPS
-__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps[4 * 32];          // [wave][slot]
 __device__ __forceinline__ unsigned long long stamp_now()
 {
     unsigned long long t;
@@ -67,7 +78,7 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define STAMP(slot)                                                                          \
     do {                                                                                     \
         const unsigned long long now_ = stamp_now();                                         \
-        if (threadIdx.x == 0) atomicAdd(&g_stamps[slot], now_ - stamp_prev);                 \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[(threadIdx.x >> 6) * 32 + (slot)], now_ - stamp_prev); \
         stamp_prev = now_;                                                                   \
     } while (0)
 #else
@@ -121,16 +132,21 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         tap0[i] = base[i] - (PW + 1) * CSTRIDE + 8 * kg;            // fragment address of tap (0,0), channel group 0
     }
 
+    // the accumulators start at the conv bias (4 consecutive channels per lane: one 16-B load per row block, requested
+    // together with the first weight fragments instead of after the GEMM)
     f32x4 acc[MW][NW];
 #pragma unroll
-    for (int mi = 0; mi < MW; ++mi)
+    for (int mi = 0; mi < MW; ++mi) {
+        const float4 bq = *reinterpret_cast<const float4 *>(lp.bias + (m0 + mi) * 16 + 4 * kg);
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
+        for (int i = 0; i < NW; ++i) { acc[mi][i][0] = bq.x; acc[mi][i][1] = bq.y; acc[mi][i][2] = bq.z; acc[mi][i][3] = bq.w; }
+    }
 
     const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
-    constexpr int AD = 3;                                            // weight fragments are requested AD k-steps ahead (L2 latency; 2 and 4 measured equal)
+#ifndef POL_AD
+#define POL_AD 3
+#endif
+    constexpr int AD = POL_AD;                                       // weight fragments are requested AD k-steps ahead (L2 latency)
     bf16x8 a[AD + 1][MW], b[NW];
 #pragma unroll
     for (int d = 0; d < AD; ++d)
@@ -150,51 +166,66 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSTRIDE + kcn * 32;
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
+        POL_PIN();
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            if (!RAGGED || i < ncount) {
+            {
 #pragma unroll
                 for (int mi = 0; mi < MW; ++mi)
                     acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
             }
             b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
+            POL_PIN();
         }
     }
 
     STAMP(1 + layer);                                                // GEMM
-    // bias (+ residual) and the LayerNorm statistics
+    // LayerNorm affine parameters of ALL this wave's tiles are requested now -- fp16 [pixel][COUT/4][8] = {weight x4, bias x4}
+    // of 4 consecutive channels, ONE 16-byte load per tile -- so that their L2 round trip overlaps the statistics and the
+    // barrier (the weight / activation fragment registers of the GEMM are dead here).  Requested group by group inside the
+    // epilogue they cost 15 % of the kernel (a build without them: 1.08 vs 1.27 ms; profiles/r02_trunk_knockouts.md).
+    f16x8 ln[SAVE ? 1 : MW][SAVE ? 1 : NW];
+    if constexpr (!SAVE) {
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                ln[mi][i] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(lp.ln) +
+                                                             ((size_t)min(pix[i], P - 1) * COUT + (m0 + mi) * 16 + 4 * kg) * 2);
+            }
+        POL_PIN();
+    }
+    // (+ residual) and the LayerNorm statistics
+    static_assert(!RAGGED, "tile ownership is 5 or 10 full-width tiles per wave");
+    (void)ncount;
+    const float vlast = pix[NW - 1] < P ? 1.0f : 0.0f;
     float s = 0.0f, ss = 0.0f;
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         const int ch0 = (m0 + mi) * 16 + 4 * kg;
-        const float4 bq = *reinterpret_cast<const float4 *>(lp.bias + ch0);
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            float x0 = acc[mi][i][0] + bq.x, x1 = acc[mi][i][1] + bq.y, x2 = acc[mi][i][2] + bq.z, x3 = acc[mi][i][3] + bq.w;
+            float x0 = acc[mi][i][0], x1 = acc[mi][i][1], x2 = acc[mi][i][2], x3 = acc[mi][i][3];
             if (RESIDUAL) {
                 const bf16x4 rq = *reinterpret_cast<const bf16x4 *>(tile + base[i] + ch0);
                 x0 += (float)rq[0]; x1 += (float)rq[1]; x2 += (float)rq[2]; x3 += (float)rq[3];
+                acc[mi][i][0] = x0; acc[mi][i][1] = x1; acc[mi][i][2] = x2; acc[mi][i][3] = x3;
             }
-            acc[mi][i][0] = x0; acc[mi][i][1] = x1; acc[mi][i][2] = x2; acc[mi][i][3] = x3;
-            if (i < ncount && pix[i] < P) {
-                s += (x0 + x1) + (x2 + x3);
-                ss += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
-            }
+            // only the wave's LAST tile can hold columns past pixel 149 (150 = 9 x 16 + 6): every other tile is summed
+            // unconditionally and the last one through a 0 / 1 factor -- no exec-mask branch per tile (the per-tile `if`
+            // compiled to 20 s_and_saveexec / s_cbranch pairs with out-of-line bodies per layer and wave)
+            const float t1 = (x0 + x1) + (x2 + x3), t2 = (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+            if (i + 1 < NW) { s += t1; ss += t2; }
+            else { s = fmaf(vlast, t1, s); ss = fmaf(vlast, t2, ss); }
         }
     }
-    // LayerNorm parameters travel in groups of G tiles (one L2 round trip per group, G x 4 registers per lane).
-    // lp.ln: fp16 [pixel][COUT/4][8] = {weight x4, bias x4} of 4 consecutive channels: ONE 16-byte load per tile.
-    // (Requesting group g+1 before group g is consumed, or group 0 before the statistics reduction, was measured:
-    // the double buffer spills and is slower, the early request stopped mattering once the parameters were fp16.)
-    constexpr int G = NW < 5 ? NW : 5, GPM = NW / G, NG = MW * GPM;
-    static_assert(NW % G == 0, "tiles per wave must be a multiple of the parameter group");
-    f16x8 ln[G];
     s = wave_sum(s);
     ss = wave_sum(ss);
     const int wave = threadIdx.x >> 6;
     if (lane == 0) { red[wave] = s; red[WAVES + wave] = ss; }
+    STAMP(14 + layer);                                               // bias / residual / statistics of this wave
     __syncthreads();
-    STAMP(5 + layer);                                                // statistics + barrier
+    STAMP(5 + layer);                                                // wait at the statistics barrier
     const float cnt = (float)(COUT * P);
     float S = 0.0f, SS = 0.0f;
 #pragma unroll
@@ -215,7 +246,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             const int ch0 = (m0 + mi) * 16 + 4 * kg;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                if (i < ncount && pix[i] < P) {
+                if (i + 1 < NW || pix[i] < P) {
                     bf16x4 xq;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xq[e] = (bf16)fmaf(acc[mi][i][e], rstd, shift);
@@ -244,31 +275,56 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         __syncthreads();
     } else {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int mi = g / GPM, i0 = (g - mi * GPM) * G, ch0 = (m0 + mi) * 16 + 4 * kg;
+        for (int mi = 0; mi < MW; ++mi) {
+            const int ch0 = (m0 + mi) * 16 + 4 * kg;
 #pragma unroll
-        for (int j = 0; j < G; ++j)
-            ln[j] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(lp.ln) + ((size_t)min(pix[i0 + j], P - 1) * COUT + ch0) * 2);
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int i = i0 + j;
-            if (i < ncount && pix[i] < P) {
-                bf16x4 o;
-                const f16x8 q = ln[j];
-                o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), (float)q[0], (float)q[4]), 0.0f);
-                o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), (float)q[1], (float)q[5]), 0.0f);
-                o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), (float)q[2], (float)q[6]), 0.0f);
-                o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), (float)q[3], (float)q[7]), 0.0f);
-                // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
-                // above, and the residual read of this lane's own elements precedes this write
-                *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
+            for (int i = 0; i < NW; ++i) {
+                if (i + 1 < NW || pix[i] < P) {
+                    bf16x4 o;
+                    const f16x8 q = ln[mi][i];
+                    o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), (float)q[0], (float)q[4]), 0.0f);
+                    o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), (float)q[1], (float)q[5]), 0.0f);
+                    o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), (float)q[2], (float)q[6]), 0.0f);
+                    o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), (float)q[3], (float)q[7]), 0.0f);
+                    // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
+                    // above, and the residual read of this lane's own elements precedes this write
+                    *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
+                }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);                         // one group's parameter set live at a time
-    }
+    STAMP(18 + layer);                                               // epilogue of this wave
     __syncthreads();
     }
-    STAMP(9 + layer);                                                // epilogue + barrier
+    STAMP(9 + layer);                                                // wait at the end-of-layer barrier (SAVE: whole epilogue)
+}
+
+// Stagger of the two workgroups that share a CU.  Both run the same program over equally long samples, so once started
+// together they stay in lockstep: both in their GEMMs (fighting for the SIMD's matrix pipe), then both in their
+// statistics / epilogue phases (pipe idle).  The second workgroup to arrive on a CU therefore starts POL_STAGGER cycles
+// late, which puts its GEMMs beside the other's epilogues (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Which
+// workgroups share a CU is not defined by HIP: the arrival order is read from a per-CU counter keyed by the hardware ids.
+// Speed only -- a wrong guess costs the delay once, results never depend on it.
+#ifndef POL_STAGGER
+#define POL_STAGGER 0
+#endif
+__device__ unsigned int g_cu_arrivals[16 * 256];
+
+__device__ __forceinline__ void stagger_second_workgroup(int tid, float *red)
+{
+    if (POL_STAGGER <= 0) return;
+    if (tid == 0) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: [11:8] CU, [12] SH, [15:13] SE
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);         // HW_REG_XCC_ID [3:0]
+        const uint32_t cu = ((hw >> 8) & 0xffu) | ((xcc & 15u) << 8);
+        reinterpret_cast<unsigned int *>(red)[0] = atomicAdd(&g_cu_arrivals[cu], 1u) & 1u;
+    }
+    __syncthreads();
+    const unsigned int second = reinterpret_cast<unsigned int *>(red)[0];
+    __syncthreads();
+    if (second) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)POL_STAGGER) __builtin_amdgcn_s_sleep(32);
+    }
 }
 
 // BITS: the observation arrives as the packed bitstring inv_step writes under INV_STEP_OBS_BITS (57 words per sample).
@@ -294,6 +350,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
     }
     if (BITS && tid < OBS_WORDS && (int)blockIdx.x < N) obw[tid] = obits[(size_t)blockIdx.x * OBS_WORDS + tid];
     __syncthreads();
+    stagger_second_workgroup(tid, red);
 
     unsigned long long stamp_prev = 0;
 #ifdef INV_POLICY_STAMPS
@@ -372,7 +429,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
             conv_ln_relu<128, 128, 4, 5, false, true, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3, LayerSave{ xh3, nullptr, keep ? rs + 3 : nullptr });
         } else {
         conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
+#ifdef POL_CONV2_2x5
+        conv_ln_relu<32, 64, 2, 5, false, false>(prm.layer[1], tile, red, lane_i, (wave & 1) * 2, (wave >> 1) * 5, 5, stamp_prev, 1);
+#else
         conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
+#endif
         conv_ln_relu<64, 128, 4, 5, false, false>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2);
         conv_ln_relu<128, 128, 4, 5, false, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3);
         }
@@ -433,12 +494,14 @@ __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int l
         const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSTRIDE + kcn * 32;
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
+        POL_PIN();
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
 #pragma unroll
             for (int mi = 0; mi < MW; ++mi)
                 acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
             b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
+            POL_PIN();
         }
     }
 }
@@ -790,9 +853,9 @@ __global__ __launch_bounds__(256) void k_policy_param_grads(const bf16 *__restri
 #ifdef INV_POLICY_STAMPS
 extern "C" int inv_policy_debug_stamps(unsigned long long *out16_host, int reset)
 {
-    if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(pol::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return INV_ERR_HIP;
+    if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(pol::g_stamps), 128 * sizeof(unsigned long long)) != hipSuccess) return INV_ERR_HIP;
     if (reset) {
-        unsigned long long z[16] = { 0 };
+        unsigned long long z[128] = { 0 };
         if (hipMemcpyToSymbol(HIP_SYMBOL(pol::g_stamps), z, sizeof z) != hipSuccess) return INV_ERR_HIP;
     }
     return INV_OK;

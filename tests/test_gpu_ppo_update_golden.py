@@ -5,9 +5,12 @@ bit-equal advantages), then the fused bf16 path bounded against the reference nu
 Tolerances: the f32 GPU path runs MIOpen / hipBLASLt kernels whose summation order differs from the CPU reference:
 first minibatch losses 2e-4 abs (value loss 2e-4 rel), gradient norm 1e-3 rel; later minibatches inherit Adam's
 amplification of that noise (CPU test docstring): 2e-2 rel on the gradient norm, 5e-3 abs on the losses.
-The fused path computes the trunk in bf16 (8 significant bits): losses 3e-2 abs / 3e-2 rel, gradient norm 15 % on the
-first minibatch -- a class bound, like tests/test_gpu_fused_train.py, not parity; its GAE / normalisation / loss /
-clip / Adam code is the same code the f32 path pins."""
+The fused path computes the trunk in bf16 (8 significant bits) -- a class bound, like tests/test_gpu_fused_train.py, not
+parity.  First minibatch (same weights as the reference, so only the bf16 forward / backward differs; measured on MI355X:
+policy loss 1e-4, value loss 9e-4 abs, entropy 4e-6, gradient norm 0.3 %): policy loss and entropy 2e-3 abs, value loss
+1e-3 rel, gradient norm 3 %.  Later minibatches start from weights that already differ by bf16-sized gradient noise times
+Adam's sign-like steps, on 32-sample minibatches (measured up to 0.031 on the policy loss): policy loss 0.1 abs, entropy
+2e-2 abs, value loss 5 %, final parameter |sums| 2 %."""
 import os
 import sys
 
@@ -62,9 +65,11 @@ def test_fused_update_stays_within_bf16_of_the_reference_update(case):
     mb = stats["minibatches"]
     dev = {k: np.abs(mb[k] - g[f"{case}_mb_{k}"]) for k in ("policy_loss", "value_loss", "entropy", "grad_norm")}
     print(case, "fused", {k: float(v.max()) for k, v in dev.items()}, "first", {k: float(v[0]) for k, v in dev.items()})
-    np.testing.assert_allclose(mb["policy_loss"], g[f"{case}_mb_policy_loss"], atol=3e-2)
-    np.testing.assert_allclose(mb["entropy"], g[f"{case}_mb_entropy"], atol=3e-2)
-    np.testing.assert_allclose(mb["value_loss"], g[f"{case}_mb_value_loss"], rtol=3e-2)
-    assert dev["grad_norm"][0] < 0.15 * g[f"{case}_mb_grad_norm"][0]
+    assert dev["policy_loss"][0] < 2e-3 and dev["entropy"][0] < 2e-3
+    assert dev["value_loss"][0] < 1e-3 * g[f"{case}_mb_value_loss"][0] + 1e-3
+    assert dev["grad_norm"][0] < 0.03 * g[f"{case}_mb_grad_norm"][0]
+    np.testing.assert_allclose(mb["policy_loss"], g[f"{case}_mb_policy_loss"], atol=0.1)
+    np.testing.assert_allclose(mb["entropy"], g[f"{case}_mb_entropy"], atol=2e-2)
+    np.testing.assert_allclose(mb["value_loss"], g[f"{case}_mb_value_loss"], rtol=5e-2)
     sd = policy.state_dict()
     np.testing.assert_allclose([float(v.double().abs().sum()) for v in sd.values()], g[f"{case}_abs_sums"], rtol=2e-2)
