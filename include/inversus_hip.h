@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define INV_ABI_VERSION 2
+#define INV_ABI_VERSION 3
 
 typedef enum {
     INV_OK = 0,
@@ -235,6 +235,31 @@ int  inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, fl
  * entry written.  Adding the slices gives the LayerNorm weight / bias gradients in [pixel][channel] order. */
 int  inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, float *partial, int32_t slices,
                             int32_t elems_per_sample, int32_t N, void *stream);
+
+/* ---- the scalar tail of the PPO update ------------------------------------------------------
+ * inv_ppo_loss: forward AND backward of the reference's minibatch loss (inversus_rl/ppo_agent.py:211-224)
+ *     loss = mean(-min(ratio A, clamp(ratio, 1-c, 1+c) A)) + value_coef mean((v - R)^2) - entropy_coef mean(entropy)
+ * over B samples with 13 logits each, one kernel: dlogits f32 [B][13] and dvalues f32 [B] receive d loss / d logits and
+ * d loss / d values (what autograd returns for the same expression, including the 1/B of the means); partial_sums f32
+ * [inv_ppo_loss_blocks(B)][3] receives per-block sums of the policy term, the squared value error and the entropy (add
+ * them and divide by B for the three means the reference reports, ppo_agent.py:234-236).  actions: int64 [B]. */
+int32_t inv_ppo_loss_blocks(int32_t B);
+int  inv_ppo_loss(const float *logits, const float *values, const int64_t *actions, const float *old_log_probs,
+                  const float *advantages, const float *returns, int32_t B, float clip_ratio, float value_coef,
+                  float entropy_coef, float *dlogits, float *dvalues, float *partial_sums, void *stream);
+/* inv_clip_adam_step: torch.nn.utils.clip_grad_norm_(params, max_grad_norm) followed by torch.optim.Adam.step()
+ * (ppo_agent.py:227-232; no weight decay, no amsgrad) over ONE flat f32 buffer of n parameters with its gradient and
+ * moment buffers (16-byte aligned), two launches, no host synchronisation:
+ *     total = |grad_scale| * ||grads||_2;  coef = min(1, max_grad_norm / (total + 1e-6))   (max_grad_norm <= 0: no clipping)
+ *     g = coef * grad_scale * grads;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+ *     params -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ * grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce; 1 otherwise).  `grads` is not modified.
+ * step: 1 for the first call.  workspace: inv_clip_adam_workspace_bytes() bytes of device memory; after the call its last
+ * 4 bytes hold `total` (the pre-clip norm clip_grad_norm_ returns) as f32 at byte offset workspace_bytes - 8. */
+int64_t inv_clip_adam_workspace_bytes(void);
+int  inv_clip_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                        float beta1, float beta2, float eps, int32_t step, float max_grad_norm, float grad_scale,
+                        void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

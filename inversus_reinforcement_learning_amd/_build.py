@@ -7,7 +7,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libinversus_hip.so")
-SOURCES = [os.path.join(CSRC, "inv_api.hip"), os.path.join(CSRC, "inv_gae.hip"), os.path.join(CSRC, "inv_policy.hip")]
+SOURCES = [os.path.join(CSRC, "inv_api.hip"), os.path.join(CSRC, "inv_gae.hip"), os.path.join(CSRC, "inv_policy.hip"),
+           os.path.join(CSRC, "inv_optim.hip")]
 HEADERS = [os.path.join(CSRC, "inv_device.h"), os.path.join(CSRC, "inv_internal.h"), os.path.join(ROOT, "include", "inversus_hip.h")]
 
 # -ffp-contract=off: the reward is an f64 sum in the reference's order and GAE is strict f32

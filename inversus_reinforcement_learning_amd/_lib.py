@@ -90,6 +90,11 @@ SIGNATURES = {
     "inv_policy_trunk_bwd": (C.c_int, [P(InvPolicyBwdParams), P(InvPolicySaved), _V, P(InvPolicyGrads), C.c_int32, _V]),
     "inv_policy_wgrad": (C.c_int, [C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_param_grads": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V]),
+    "inv_ppo_loss_blocks": (C.c_int32, [C.c_int32]),
+    "inv_ppo_loss": (C.c_int, [_V, _V, _V, _V, _V, _V, C.c_int32, C.c_float, C.c_float, C.c_float, _V, _V, _V, _V]),
+    "inv_clip_adam_workspace_bytes": (C.c_int64, []),
+    "inv_clip_adam_step": (C.c_int, [_V, _V, _V, _V, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float,
+                                     C.c_float, _V, _V]),
 }
 
 _lib = None

@@ -115,7 +115,9 @@ class FlatGradReducer:
                                    "zero gradients with reducer.zero()")
             off += p.numel()
 
-    def reduce(self):
+    def reduce(self, average=True):
+        """All-reduce the bucket (SUM); average=True also divides by the world size (False: the caller scales, e.g. inside the
+        fused Adam kernel)."""
         self._check_aliases()
         _, w = world()
         if initialized():
@@ -126,7 +128,8 @@ class FlatGradReducer:
             else:                                           # no hooks fired (no early set, or a parameter went unused)
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self._work = None
-            self.flat.div_(w)
+            if average:
+                self.flat.div_(w)
 
 
 def global_mean_std(x):

@@ -45,10 +45,17 @@ class PPOAgent:
         self.update_autocast = update_autocast
         # fused_update: the minibatch forward / backward of the conv trunk runs in the fused HIP kernels
         # (fused_train.py; bf16 operands like update_autocast=bf16, ~4x less time than autograd over the module)
+        # and the scalar tail runs in csrc/inv_optim.hip: the minibatch loss with its backward as one kernel, clip_grad_norm_ +
+        # Adam over one flat parameter buffer as two launches (flat_optim.py) instead of ~100 small torch kernels.
         self.train_fwd = None
+        self.flat_adam = None
         if fused_update:
             from .fused_train import FusedTrainPolicy
+            from .flat_optim import FlatAdam
             self.train_fwd = FusedTrainPolicy(self.policy)
+            order = self.reducer.params if self.reducer is not None else [p for p in self.policy.parameters() if p.requires_grad]
+            self.flat_adam = FlatAdam(order, lr=lr, max_grad_norm=max_grad_norm,
+                                      grad_flat=self.reducer.flat if self.reducer is not None else None)
         self.fused = None
         if fused_act:
             from .fused_policy import FusedPolicy
@@ -187,25 +194,40 @@ class PPOAgent:
                                         enabled=self.update_autocast is not None):
                         logits, values = self.policy(self._planes(obs_grid[idx]), obs_extra[idx])
                 logits, values = logits.float(), values.float()
-                dist = torch.distributions.Categorical(logits=logits, validate_args=False)
-                new_log_probs = dist.log_prob(actions[idx])
-                entropy = dist.entropy().mean()
-                ratio = torch.exp(new_log_probs - old_log_probs[idx])
-                adv = advantages[idx]
-                surr1 = ratio * adv
-                surr2 = torch.clamp(ratio, 1.0 - self.clip_ratio, 1.0 + self.clip_ratio) * adv
-                policy_loss = -torch.min(surr1, surr2).mean()
-                value_loss = nn.functional.mse_loss(values.squeeze(-1), returns[idx])
-                loss = policy_loss + self.value_coef * value_loss - self.entropy_coef * entropy
-                if self.reducer is not None:
-                    self.reducer.zero()                                   # grads accumulate into the flat bucket
-                    loss.backward()
-                    self.reducer.reduce()                                 # ONE RCCL all-reduce per optimizer step
+                if self.flat_adam is not None:                            # HIP loss (+ its backward) and clip + Adam kernels
+                    from .flat_optim import ppo_loss
+                    loss, means = ppo_loss(logits, values.squeeze(-1), actions[idx], old_log_probs[idx], advantages[idx], returns[idx],
+                                           self.clip_ratio, self.value_coef, self.entropy_coef)
+                    if self.reducer is not None:
+                        self.reducer.zero()
+                        loss.backward()
+                        self.reducer.reduce(average=False)                # SUM over ranks; the 1/world_size rides in the Adam kernel
+                        grad_norm = self.flat_adam.step(grad_scale=1.0 / parallel.world()[1])
+                    else:
+                        self.flat_adam.zero_grad()
+                        loss.backward()
+                        grad_norm = self.flat_adam.step()
+                    policy_loss, value_loss, entropy = means[0], means[1], means[2]
                 else:
-                    self.optimizer.zero_grad()
-                    loss.backward()
-                grad_norm = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-                self.optimizer.step()
+                    dist = torch.distributions.Categorical(logits=logits, validate_args=False)
+                    new_log_probs = dist.log_prob(actions[idx])
+                    entropy = dist.entropy().mean()
+                    ratio = torch.exp(new_log_probs - old_log_probs[idx])
+                    adv = advantages[idx]
+                    surr1 = ratio * adv
+                    surr2 = torch.clamp(ratio, 1.0 - self.clip_ratio, 1.0 + self.clip_ratio) * adv
+                    policy_loss = -torch.min(surr1, surr2).mean()
+                    value_loss = nn.functional.mse_loss(values.squeeze(-1), returns[idx])
+                    loss = policy_loss + self.value_coef * value_loss - self.entropy_coef * entropy
+                    if self.reducer is not None:
+                        self.reducer.zero()                               # grads accumulate into the flat bucket
+                        loss.backward()
+                        self.reducer.reduce()                             # ONE RCCL all-reduce per optimizer step
+                    else:
+                        self.optimizer.zero_grad()
+                        loss.backward()
+                    grad_norm = torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                    self.optimizer.step()
                 if trace:
                     mb_trace.append(torch.stack([policy_loss.detach(), value_loss.detach(), entropy.detach(), grad_norm.detach()]))
                 tot_p += policy_loss.detach()

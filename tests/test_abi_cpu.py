@@ -32,7 +32,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in include/inversus_hip.h but not exported"
     lib = _lib.load()
     assert set(_lib.SIGNATURES) == set(declared_symbols())
-    assert lib.inv_abi_version() == 2
+    import re
+    with open(os.path.join(ROOT, "include", "inversus_hip.h")) as fh:
+        assert lib.inv_abi_version() == int(re.search(r"#define\s+INV_ABI_VERSION\s+(\d+)", fh.read()).group(1)) == 3
 
 
 def test_code_object_is_gfx950():
