@@ -20,7 +20,7 @@
  *     aligned 32-bit words through the scalar cache: the ALLOCATION behind each of them must
  *     extend to the next 4-byte boundary past its last byte (hipMalloc and torch allocations
  *     always do; a hand-carved sub-buffer at the very end of an allocation of odd size must be
- *     padded).  The extra bytes are never interpreted.
+ *     padded).  The extra bytes are never interpreted; nothing beyond that boundary is read.
  *   - return value: INV_OK or a negative inv_status; inv_last_error() gives text.
  *   - env i of a handle has GLOBAL index env_offset + i (multi-GPU sharding: one
  *     handle per rank over a contiguous global range; results do not depend on
@@ -127,6 +127,14 @@ int  inv_abi_version(void);
 int  inv_create(const inv_config *cfg, inv_handle **out);
 int  inv_destroy(inv_handle *h);
 int  inv_get_config(const inv_handle *h, inv_config *cfg);
+/* Which kernel runs FULL, unmasked steps (inv_step with INV_STEP_DEFAULT, inv_rollout).  Results are identical; this is a
+ * speed knob and the hook the parity tests use to run every case through both.
+ *   AUTO  four envs per wavefront (csrc/inv_step4.h) where it exists and measured faster or equal (15x10 boards; 32x32
+ *         boards with packed observations; max_bullets = 16), else WAVE
+ *   WAVE  one env per wavefront (csrc/inv_device.h); always used for partial-phase and masked steps
+ *   ROW4  as AUTO, but an error where the four-env kernel does not exist */
+enum { INV_STEP_KERNEL_AUTO = 0, INV_STEP_KERNEL_WAVE = 1, INV_STEP_KERNEL_ROW4 = 2 };
+int  inv_set_step_kernel(inv_handle *h, int32_t kind);
 /* bytes of one env's obs / words per grid, for sizing caller buffers */
 int64_t inv_obs_floats_per_env(const inv_handle *h);   /* 12*H*W */
 int32_t inv_grid_words(const inv_handle *h);           /* GW */

@@ -9,7 +9,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libinversus_hip.so")
 SOURCES = [os.path.join(CSRC, "inv_api.hip"), os.path.join(CSRC, "inv_gae.hip"), os.path.join(CSRC, "inv_policy.hip"),
            os.path.join(CSRC, "inv_optim.hip")]
-HEADERS = [os.path.join(CSRC, "inv_device.h"), os.path.join(CSRC, "inv_internal.h"), os.path.join(ROOT, "include", "inversus_hip.h")]
+HEADERS = [os.path.join(CSRC, "inv_device.h"), os.path.join(CSRC, "inv_step4.h"), os.path.join(CSRC, "inv_internal.h"), os.path.join(ROOT, "include", "inversus_hip.h")]
 
 # -ffp-contract=off: the reward is an f64 sum in the reference's order and GAE is strict f32
 # (ppo_agent.py:145-152); an FMA contraction would change results.

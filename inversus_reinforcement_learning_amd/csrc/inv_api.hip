@@ -3,11 +3,13 @@
 // gfx950 only.  One wavefront per env (see inv_device.h); 4 envs per 256-thread block, no
 // workgroup barriers.  Every entry point is asynchronous on the caller's stream.
 #include "inv_device.h"
+#include "inv_step4.h"
 #include "inv_internal.h"
 
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
 {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (kWave - 1), wv = rfl((int)(threadIdx.x >> 6));   // wave index: uniform -> SGPR
-    const int env = blockIdx.x * kWavesPerBlock + wv;
+    const int env = xcd_block((int)blockIdx.x, (int)gridDim.x) * kWavesPerBlock + wv;
     const int N = a.d.N;
     if (env >= N) return;                           // wave-uniform; no block barriers below
     if (a.mask && sload_u8(a.mask, (size_t)env) == 0u) return;
@@ -196,6 +198,141 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
         fs.head = ka->s.head; fs.grid = ka->s.grid; fs.bullets = ka->s.bullets; fs.mt = nullptr; fs.err = ka->s.err; fs.prox = nullptr;
         store_env(d, fs, env, lane, g, e);
         if (err && lane == 0) atomicOr(fs.err, err);
+    }
+}
+
+
+// The same step with FOUR envs per wave (inv_step4.h): full steps only (all four phases), no mask.  WPB waves per block.
+template <class D, bool SINGLE, int WPB>
+__global__ __launch_bounds__(kWave * WPB) void k_step4(StepArgs a)
+{
+    using namespace inv4;
+    using LL = Lds4<D>;
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (kWave - 1), wv = rfl((int)(threadIdx.x >> 6));
+    const int l = lane & (kRowLanes - 1), r = lane >> 4;
+    const int N = a.d.N;
+    const int env0 = (xcd_block((int)blockIdx.x, (int)gridDim.x) * WPB + wv) * kRows;   // first env of this wave (uniform)
+    if (env0 >= N) return;
+    const int env = env0 + r;
+    const bool valid = env < N;
+    const int envc = valid ? env : 0;
+    uint32_t *wl = lds + wv * LL::wave_words;
+    uint32_t *rowp = wl + kTabWords + r * LL::row_words;
+    uint32_t *g = rowp + 8, *slots = g + LL::GWp, *reg = slots + 16, *mtscr = wl + kTabWords + kRows * LL::row_words;
+    const float4 *tab = reinterpret_cast<const float4 *>(wl);
+    init_nibble_table(reinterpret_cast<float *>(wl), lane);
+    const D d(a.d);
+    // the proximity table (env_wrappers.py:382) lives in the wave's MT scratch between resets: a per-row LDS read instead of a
+    // vector load that would queue behind the previous step's observation stores in the multi-step kernel
+    double *proxl = reinterpret_cast<double *>(mtscr);
+    for (int q = lane; q <= D::W + D::H; q += kWave) proxl[q] = a.s.prox[q];
+
+    Row e;
+    load_rows<D>(a.s, env, l, valid, rowp, e);
+    uint32_t err = 0u;
+    const bool obits = (a.flags & INV_STEP_OBS_BITS) != 0u;
+    const size_t obs_stride = obits ? (size_t)D::OW : (size_t)12 * D::WH;
+    const bool auto_reset = (a.flags & INV_STEP_AUTO_RESET) != 0u;
+    const uint32_t genv = a.env_offset + (uint32_t)envc;
+
+    const int T = SINGLE ? 1 : a.T;
+    for (int t = 0; t < T; ++t) {
+        const size_t idx = (size_t)t * N + envc;
+        const size_t idx0 = (size_t)t * N + env0;                            // wave-uniform: the four envs' action bytes are adjacent
+        const int act1 = (int)((sload_u8x4(a.a1, idx0, (size_t)T * N) >> (8 * r)) & 255u);
+        int act2;
+        if (a.a2) {
+            act2 = (int)((sload_u8x4(a.a2, idx0, (size_t)T * N) >> (8 * r)) & 255u);
+        } else {
+            act2 = dummy_action4<D>(g, lane, l, e, a.hard, a.opp_seed, genv);
+            e.opp_ctr += 1u;
+        }
+        const bool bad = act1 > 12 || act2 > 12;                            // ValueError in the reference (env_wrappers.py:66): env untouched
+        const bool ok = !bad;
+        err |= bad ? ERR_BAD_ACTION : 0u;
+
+        apply_action4<D, 0>(g, l, act1, ok, e, err);                        // core.py:510-525: P1 then P2
+        apply_action4<D, 1>(g, l, act2, ok, e, err);
+        reload4(e.al1, e.am1, e.rl1, ok);                                   // :528
+        reload4(e.al2, e.am2, e.rl2, ok);
+        const int tile_diff = update_bullets4<D>(g, slots, reg, lane, l, ok, e);   // :531
+
+        // env_wrappers.py:333-442, f64 adds in the reference's order (every skipped term is +0.0: the running sum is never -0.0)
+        double reward = 0.0;
+        int done = 0;
+        uint32_t info = 0u;
+        {
+            const int sc = e.step_count + 1;
+            const int al1 = e.al1, al2 = e.al2, both = al1 & al2, over = both ^ 1;
+            const int landed = e.prev2 & (al2 ^ 1), got = e.prev1 & (al1 ^ 1);
+            const int win = al1 & (al2 ^ 1), lose = al2 & (al1 ^ 1);
+            const int xeq = e.x1 == e.x2, yeq = e.y1 == e.y2, aligned = xeq | yeq;
+            const int dist = abs(e.x1 - e.x2) + abs(e.y1 - e.y2);
+            const int shot = (act1 - 1) & 3;
+            const int aim_v = ((e.y1 < e.y2) & (shot == 2)) | ((e.y1 > e.y2) & (shot == 0));
+            const int aim_h = ((e.x1 < e.x2) & (shot == 1)) | ((e.x1 > e.x2) & (shot == 3));
+            const int aiming = both & aligned & (act1 >= 5) & (e.am1 > 0) & (xeq ? aim_v : aim_h);
+            const int timeout = sc >= a.d.max_steps;
+            const double prox = proxl[dist];                                 // dist <= W + H - 2: always in the table
+            double rw = 0.0;
+            rw += tile_diff > 0 ? (double)tile_diff * 0.01 : 0.0;             // :349-354
+            rw += landed ? 1.0 : 0.0;                                         // :357-362
+            rw += got ? -0.01 : 0.0;                                          // :364-369
+            rw += (al1 & (e.am1 == 0)) ? -0.001 : 0.0;                        // :372-373
+            rw += both ? prox : 0.0;                                          // :378-382
+            rw += (both & aligned) ? 0.002 : 0.0;                             // :385-387
+            rw += aiming ? 0.05 : 0.0;                                        // :391-405
+            rw += over ? (win ? 10.0 : (lose ? -0.1 : 0.0)) : -0.001;         // :408-427
+            rw += (timeout & both) ? -2.0 : 0.0;                              // :434-438
+            if (ok) {
+                reward = rw;
+                done = over | timeout;
+                info = (uint32_t)(landed * INV_INFO_LANDED_HIT | got * INV_INFO_GOT_HIT | (over & win) * INV_INFO_WIN | (over & lose) * INV_INFO_LOSE);
+                e.step_count = sc;
+                e.prev1 = al1;
+                e.prev2 = al2;
+                e.ep_ret += rw;
+            }
+        }
+        if (l == 0 && valid) {
+            if (a.o.reward) a.o.reward[idx] = (float)reward;
+            if (a.o.reward64) a.o.reward64[idx] = reward;
+            if (a.o.done) a.o.done[idx] = (uint8_t)done;
+            if (a.o.info_flags) a.o.info_flags[idx] = (uint8_t)info;
+            if (a.o.episode_steps) a.o.episode_steps[idx] = e.step_count;
+            if (a.o.episode_return) a.o.episode_return[idx] = e.ep_ret;
+        }
+
+        // training.py:148-151: rows whose episode ended are reset one after the other by the whole wave (MT19937 of inv_device.h)
+        uint64_t need = __ballot(auto_reset && done && valid && l == 0);
+        while (need) {
+            const int rl = __ffsll((unsigned long long)need) - 1;           // lane 16 * row
+            need &= need - 1;
+            const int rr = rl >> 4;
+            Env et;
+            et.mti = (int)rdlane((uint32_t)e.mti, rl);
+            uint32_t *rg = wl + kTabWords + rr * LL::row_words + 8;
+            reset_env(d, a.s, env0 + rr, lane, rg, mtscr, et);               // may use the MT scratch: restore the table
+            for (int q = lane; q <= D::W + D::H; q += kWave) proxl[q] = a.s.prox[q];
+            wave_sync();
+            if (r == rr) {
+                e.x1 = et.p[0].x; e.y1 = et.p[0].y; e.am1 = 6; e.rl1 = 0; e.al1 = 1;
+                e.x2 = et.p[1].x; e.y2 = et.p[1].y; e.am2 = 6; e.rl2 = 0; e.al2 = 1;
+                e.nb = 0; e.bw = 0u; e.step_count = 0; e.ep_ret = 0.0; e.prev1 = e.prev2 = 1; e.mti = et.mti;
+            }
+        }
+
+        const int nvalid = min(kRows, N - env0);                            // rows of this wave that are envs
+        const size_t idxr = (size_t)t * N + env;                            // this row's slot (past the end for rows >= nvalid: never written)
+        if (a.o.obs) render4<D>(g, reg, tab, lane, 0, e, valid, nvalid, LL::row_words, a.o.obs + idxr * obs_stride, a.o.extra ? a.o.extra + idxr * 4 : nullptr, obits);
+        if (a.o.obs_p2) render4<D>(g, reg, tab, lane, 1, e, valid, nvalid, LL::row_words, a.o.obs_p2 + idxr * obs_stride, a.o.extra_p2 ? a.o.extra_p2 + idxr * 4 : nullptr, obits);
+    }
+    store_rows<D>(a.s, env, l, valid, rowp, e);
+    // rows past N step a copy of env 0 on whatever bytes follow the action buffer: their state is never stored and their
+    // errors are not errors
+    if (__ballot(err != 0u && valid) != 0ull) {
+        if (err && l == 0 && valid) atomicOr(a.s.err, err);
     }
 }
 
@@ -384,6 +521,7 @@ struct inv_handle {
     uint32_t *keys;      // [N][2] staging for inv_seed, followed by N mask bytes
     uint32_t *keys_host; // pinned, same layout
     int lds_bytes;
+    int step4_mode;      // full unmasked steps: 0 wave-per-env kernel, 1 auto (see launch_step), 2 four-envs-per-wave kernel
 };
 
 static thread_local char g_err[512] = "";
@@ -462,6 +600,7 @@ int inv_create(const inv_config *cfg, inv_handle **out)
     d.scr_words = scr_words_for(d.GW, d.K, d.OW);     // table + grid + slots + scratch, 16-B multiple
     d.max_steps = cfg->max_episode_steps;
     h->lds_bytes = d.scr_words * 4 * kWavesPerBlock;
+    h->step4_mode = 1;
 
     const size_t n = (size_t)d.N;
     HIP_TRY(hipMalloc(&h->s.head, n * kHeadWords * sizeof(uint32_t)));
@@ -505,6 +644,18 @@ int inv_destroy(inv_handle *h)
         if (p) (void)hipFree(p);
     if (h->keys_host) (void)hipHostFree(h->keys_host);
     delete h;
+    return INV_OK;
+}
+
+int inv_set_step_kernel(inv_handle *h, int32_t kind)
+{
+    if (!h) return fail(INV_ERR_BAD_ARG, "inv_set_step_kernel: NULL handle");
+    if (kind != INV_STEP_KERNEL_AUTO && kind != INV_STEP_KERNEL_WAVE && kind != INV_STEP_KERNEL_ROW4)
+        return fail(INV_ERR_BAD_ARG, "inv_set_step_kernel: unknown kind %d", (int)kind);
+    const bool row4_ok = h->d.K == 16 && ((h->d.W == 15 && h->d.H == 10) || (h->d.W == 32 && h->d.H == 32));
+    if (kind == INV_STEP_KERNEL_ROW4 && !row4_ok)
+        return fail(INV_ERR_BAD_ARG, "inv_set_step_kernel: the four-envs-per-wave kernel exists for 15x10 and 32x32 boards with max_bullets = 16");
+    h->step4_mode = kind == INV_STEP_KERNEL_WAVE ? 0 : (kind == INV_STEP_KERNEL_ROW4 ? 2 : 1);
     return INV_OK;
 }
 
@@ -567,6 +718,31 @@ static int launch_step(inv_handle *h, int T, const uint8_t *mask, const uint8_t 
     a.opp_seed = h->cfg.opp_seed;
     a.env_offset = (uint32_t)h->cfg.env_offset;
     a.T = T;
+    // Full steps without a mask on the two static board sizes: four envs per wave (inv_step4.h) unless inv_set_step_kernel chose
+    // the wave-per-env kernel (A/B runs; the parity tests go through both).
+    const bool full = (flags & INV_STEP_DEFAULT) == INV_STEP_DEFAULT && !mask && h->d.K == 16;
+    // AUTO: the four-env kernel wherever it measured equal or faster (profiles/r02_step_kernel_ab.json): every 15x10 step, and
+    // the 32x32 board with packed observations; 32x32 with f32 planes (0.8 GB of stores per step, store-bound either way)
+    // stays on the wave-per-env kernel, which was 4 % faster there.
+    const bool bits = (flags & INV_STEP_OBS_BITS) != 0u;
+    if (h->step4_mode && full && h->d.W == 15 && h->d.H == 10) {
+        using DT = StaticDims<15, 10, 16>;
+        constexpr int WPB = 4, lds = inv4::Lds4<DT>::wave_words * 4 * WPB;
+        const int blocks = (h->d.N + inv4::kRows * WPB - 1) / (inv4::kRows * WPB);
+        if (T == 1) hipLaunchKernelGGL((k_step4<DT, true, WPB>), dim3(blocks), dim3(kWave * WPB), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_step4<DT, false, WPB>), dim3(blocks), dim3(kWave * WPB), lds, (hipStream_t)stream, a);
+        HIP_TRY(hipGetLastError());
+        return INV_OK;
+    }
+    if ((h->step4_mode == 2 || (h->step4_mode == 1 && bits)) && full && h->d.W == 32 && h->d.H == 32) {
+        using DT = StaticDims<32, 32, 16>;
+        constexpr int WPB = 2, lds = inv4::Lds4<DT>::wave_words * 4 * WPB;
+        const int blocks = (h->d.N + inv4::kRows * WPB - 1) / (inv4::kRows * WPB);
+        if (T == 1) hipLaunchKernelGGL((k_step4<DT, true, WPB>), dim3(blocks), dim3(kWave * WPB), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_step4<DT, false, WPB>), dim3(blocks), dim3(kWave * WPB), lds, (hipStream_t)stream, a);
+        HIP_TRY(hipGetLastError());
+        return INV_OK;
+    }
     if (T == 1)
         INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL((k_step<DT, true>), dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock),
                                                    h->lds_bytes, (hipStream_t)stream, a));

@@ -5,6 +5,7 @@ computation happens in libinversus_hip.so (csrc/).  All methods are asynchronous
 current torch stream unless they return host data.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -32,7 +33,9 @@ class StepResult:
 
 class DeviceEnvBatch:
     def __init__(self, num_envs, width=15, height=10, max_bullets=16, max_episode_steps=500,
-                 opponent="dummy", difficulty="easy", device=None, opp_seed=0, env_offset=0):
+                 opponent="dummy", difficulty="easy", device=None, opp_seed=0, env_offset=0, step_kernel=None):
+        """step_kernel: "auto" (default; env INVERSUS_STEP_KERNEL overrides the default), "wave" or "row4" -- which kernel runs
+        full steps (inv_set_step_kernel); results are identical."""
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("inversus_reinforcement_learning_amd needs a ROCm GPU (torch.cuda is unavailable); "
@@ -56,6 +59,15 @@ class DeviceEnvBatch:
         with torch.cuda.device(self.device):
             L.raise_for(self.lib.inv_create(C.byref(cfg), C.byref(h)), self.lib)
         self.h = h
+        kind = (step_kernel or os.environ.get("INVERSUS_STEP_KERNEL") or "auto").lower()
+        if kind == "row4_if_any":                                       # the parity tests: force the four-env kernel where it exists
+            kind = "row4" if (self.K == 16 and (self.W, self.H) in ((15, 10), (32, 32))) else "auto"
+        if kind not in ("auto", "wave", "row4"):
+            raise ValueError(f"step_kernel must be auto, wave or row4, got {kind!r}")
+        self.step_kernel = kind
+        if kind != "auto":
+            code = {"wave": L.INV_STEP_KERNEL_WAVE, "row4": L.INV_STEP_KERNEL_ROW4}[kind]
+            L.raise_for(self.lib.inv_set_step_kernel(self.h, code), self.lib)
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None

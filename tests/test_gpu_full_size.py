@@ -12,7 +12,7 @@ Bar: bit-exact."""
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_step_kernels")]
 
 
 def bits_eq(a, b):

@@ -5,7 +5,7 @@ f32 path of the same library; the trunk's features from bits must EQUAL its feat
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_step_kernels")]
 
 
 def make(n, W=15, H=10, **kw):

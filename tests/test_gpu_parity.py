@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_step_kernels")]
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CORE = 7      # INV_PHASE_ACTIONS | RELOAD | BULLETS (no wrapper bookkeeping)
@@ -499,4 +499,37 @@ def test_arbitrary_states_golden(torch_cuda):
     want = g["o_info"].astype(np.uint8)
     assert np.array_equal(r.info_flags.cpu().numpy(), want[:, 0] | (want[:, 1] << 1) | (want[:, 2] << 2) | (want[:, 3] << 3))
     assert np.array_equal(r.episode_steps.cpu().numpy(), g["o_steps"]) and bits_eq(r.episode_return.cpu().numpy(), g["o_epret"].astype(np.float64))
+    b.check()
+
+
+def test_action_buffers_ending_exactly_at_an_allocation_end(torch_cuda):
+    """The action bytes are fetched as aligned dwords through the scalar cache: nothing beyond the 4-byte-rounded end of a1 / a2
+    may be read (a version of the four-envs-per-wave kernel always fetched two dwords and faulted when the buffer ended at the
+    end of a mapped segment).  a1 / a2 are the last bytes of 2 MiB allocations (torch hands those out as whole segments)."""
+    torch = torch_cuda
+    from oracle import oracle as orc
+    n, T = 16384, 3
+    big1 = torch.zeros(2 * 1024 * 1024, dtype=torch.uint8, device="cuda")
+    big2 = torch.zeros(2 * 1024 * 1024, dtype=torch.uint8, device="cuda")
+    a1 = big1[-T * n:].view(T, n)
+    a2 = big2[-T * n:].view(T, n)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a1.copy_(torch.randint(0, 13, (T, n), device="cuda", generator=g, dtype=torch.uint8))
+    a2.copy_(torch.randint(0, 13, (T, n), device="cuda", generator=g, dtype=torch.uint8))
+    b = make(n, opponent="selfplay")
+    seeds = np.arange(n, dtype=np.int64)
+    b.seed(seeds); b.reset()
+    r = b.rollout(a1, a2, obs=False)                                     # multi-step kernel: t * N + env indexing up to the last byte
+    last = b.step(a1[T - 1], a2[T - 1], obs=False, auto_reset=True)      # single-step kernel on the final row of the buffer
+    ob = orc.OracleBatch(n)
+    ob.seed_reset(seeds)
+    for t in list(range(T)) + [T - 1]:                                   # the rollout's T steps, then the extra single step
+        _, _, o_r32, _, o_done, _ = ob.step(a1[t].cpu().numpy(), a2[t].cpu().numpy(), want_obs=False, nthreads=8)
+        if t < T - 1 or t == T - 1 and last is not None:
+            want_r, want_d = o_r32, o_done
+    assert bits_eq(last.reward.cpu().numpy(), want_r) and np.array_equal(last.done.cpu().numpy(), want_d)
+    o = ob.state(16)
+    s = b.get_state()
+    for k in ("grid", "players", "nbullets", "bullets", "step_count"):
+        assert np.array_equal(s[k], o[k]), k
     b.check()
