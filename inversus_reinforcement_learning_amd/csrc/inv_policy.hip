@@ -40,7 +40,23 @@ namespace pol {
 constexpr int H = 10, W = 15, P = H * W;                 // 150 pixels
 constexpr int PW = W + 2, PH = H + 2, NPOS = PW * PH;    // 12 x 17 haloed tile, 204 positions
 constexpr int OBS_WORDS = (12 * W * H + 31) / 32;          // 57 u32 words of one packed observation
-constexpr int CSTRIDE = 136;                             // bf16 per position: 128 channels + 8 pad = 272 B
+constexpr int CSTRIDE = 136;                             // bf16 per position: 128 channels + 8 pad = 272 B (backward kernel)
+// Forward kernels (POL_ROWTILES): GEMM pixel tiles are BOARD ROWS (15 pixels + one dummy column that reads the right halo) on a
+// 288-B position stride.  ds_read_b128 is served in groups of 16 lanes that mix two channel groups (lanes 0-3, 12-15 of one,
+// 4-11 of the next): with consecutive positions 72 dwords (8 banks mod 64) apart and channel groups 4 dwords apart all sixteen
+// 16-B pieces of a group fall into different banks; a tile of 16 LINEAR pixels wraps to the next board row (a +2 position
+// jump) and the 272-B stride puts lane (g, 12) on the banks of lane (g + 1, 11): 2-way conflicts on every fragment read
+// (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in round 1).  Conflict-free reads are what lets a wave own 2 row blocks x
+// ALL 10 pixel tiles: every weight fragment is then loaded by ONE wave per workgroup instead of two (0.47 instead of 0.94 MB
+// per sample through the 64 B/clk vector memory path) at twice the (now half as expensive) activation fragment reads.
+#ifndef POL_NO_ROWTILES
+#define POL_ROWTILES 1
+constexpr int CSF = 144;                                 // forward: 288 B per position
+#else
+#define POL_ROWTILES 0
+constexpr int CSF = CSTRIDE;
+#endif
+constexpr int NPOSF = NPOS + 1;                          // the dummy column of the last board row reads one position past the halo
 constexpr int THREADS = 256, WAVES = THREADS / 64;       // 4 waves per block, 2 blocks per CU (55 KB LDS each)
 constexpr float LN_EPS = 1e-5f;
 
@@ -127,9 +143,14 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     int pix[NW], base[NW], tap0[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
+#if POL_ROWTILES
+        pix[i] = (n0 + i) * W + min(c16, W - 1);                    // tile = board row n0 + i; column 15 is a dummy (never stored)
+        base[i] = ((n0 + i + 1) * PW + c16 + 1) * CSF;              // the dummy column sits on the right halo: reads zeros
+#else
         pix[i] = (n0 + i) * 16 + c16;
-        base[i] = pos_of(min(pix[i], P - 1)) * CSTRIDE;             // columns >= 150 read pixel 149; never stored
-        tap0[i] = base[i] - (PW + 1) * CSTRIDE + 8 * kg;            // fragment address of tap (0,0), channel group 0
+        base[i] = pos_of(min(pix[i], P - 1)) * CSF;                 // columns >= 150 read pixel 149; never stored
+#endif
+        tap0[i] = base[i] - (PW + 1) * CSF + 8 * kg;                // fragment address of tap (0,0), channel group 0
     }
 
     // the accumulators start at the conv bias (4 consecutive channels per lane: one 16-B load per row block, requested
@@ -163,7 +184,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         const int ksn = ks + 1 < KS ? ks + 1 : ks;                 // redundant prefetches at the end stay in bounds
         const int ksa = ks + AD < KS ? ks + AD : KS - 1;
         const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
-        const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSTRIDE + kcn * 32;
+        const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSF + kcn * 32;
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
         POL_PIN();
@@ -198,7 +219,13 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     // (+ residual) and the LayerNorm statistics
     static_assert(!RAGGED, "tile ownership is 5 or 10 full-width tiles per wave");
     (void)ncount;
+#if POL_ROWTILES
+    const bool vcol = c16 < W;                                       // the same for every tile of the lane
+    const float vlast = 1.0f;
+#else
+    const bool vcol = true;
     const float vlast = pix[NW - 1] < P ? 1.0f : 0.0f;
+#endif
     float s = 0.0f, ss = 0.0f;
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
@@ -219,6 +246,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             else { s = fmaf(vlast, t1, s); ss = fmaf(vlast, t2, ss); }
         }
     }
+    if (!vcol) { s = 0.0f; ss = 0.0f; }                              // row tiles: the dummy column's sums
     s = wave_sum(s);
     ss = wave_sum(ss);
     const int wave = threadIdx.x >> 6;
@@ -246,7 +274,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             const int ch0 = (m0 + mi) * 16 + 4 * kg;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                if (i + 1 < NW || pix[i] < P) {
+                if (POL_ROWTILES ? vcol : (i + 1 < NW || pix[i] < P)) {
                     bf16x4 xq;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xq[e] = (bf16)fmaf(acc[mi][i][e], rstd, shift);
@@ -258,7 +286,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         bf16x8 *xdst = reinterpret_cast<bf16x8 *>(sv.xhat), *adst = reinterpret_cast<bf16x8 *>(sv.act);
         for (int q = threadIdx.x; q < P * (COUT / 8); q += THREADS) {
             const int p = q / (COUT / 8), part = q - p * (COUT / 8);
-            bf16 *tp = tile + pos_of(p) * CSTRIDE + part * 8;
+            bf16 *tp = tile + pos_of(p) * CSF + part * 8;
             const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(tp);
             if (xdst) xdst[q] = xv;
             const _Float16 *lq = reinterpret_cast<const _Float16 *>(lp.ln) + ((size_t)p * COUT + part * 8) * 2;
@@ -279,7 +307,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             const int ch0 = (m0 + mi) * 16 + 4 * kg;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                if (i + 1 < NW || pix[i] < P) {
+                if (POL_ROWTILES ? vcol : (i + 1 < NW || pix[i] < P)) {
                     bf16x4 o;
                     const f16x8 q = ln[mi][i];
                     o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), (float)q[0], (float)q[4]), 0.0f);
@@ -333,7 +361,7 @@ template <bool BITS, bool SAVE>
 __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params prm, const void *__restrict__ obs_in,
                                                           bf16 *__restrict__ feat, int N, inv_policy_saved sv)
 {
-    __shared__ __attribute__((aligned(16))) bf16 tile[NPOS * CSTRIDE];         // 55 488 B: layers run in place -> 2 blocks / CU
+    __shared__ __attribute__((aligned(16))) bf16 tile[NPOSF * CSF];         // 55 488 B: layers run in place -> 2 blocks / CU
     __shared__ float red[2 * WAVES];
     __shared__ uint32_t obw[BITS ? OBS_WORDS : 1];                             // BITS: the current sample's bitstring
     const float *obs = reinterpret_cast<const float *>(obs_in);
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));   // uniform -> tile ownership and weight pointers in SGPRs
 
     // zero both tiles once: the halo and the pad channels stay zero for the life of the block
-    for (int i = tid; i < NPOS * CSTRIDE / 8; i += THREADS) {
+    for (int i = tid; i < NPOSF * CSF / 8; i += THREADS) {
         bf16x8 z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
@@ -378,7 +406,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
                     lo = (((obw[b0 >> 5] >> (b0 & 31)) & 1u) * 0x3F80u) | (((obw[b1 >> 5] >> (b1 & 31)) & 1u) * 0x3F800000u);
                     hi = (((obw[b2 >> 5] >> (b2 & 31)) & 1u) * 0x3F80u) | (((obw[b3 >> 5] >> (b3 & 31)) & 1u) * 0x3F800000u);
                 }
-                *reinterpret_cast<uint2 *>(&tile[pos_of(p) * CSTRIDE + part * 4]) = make_uint2(lo, hi);
+                *reinterpret_cast<uint2 *>(&tile[pos_of(p) * CSF + part * 4]) = make_uint2(lo, hi);
             }
         } else {
             // f32 [12][150]: both float4 loads of a thread are issued before anything is converted (one HBM round trip, not 19).
@@ -392,19 +420,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
                 const int p = z / 5, part = z - p * 5;
                 bf16x4 zz;
                 zz[0] = zz[1] = zz[2] = zz[3] = (bf16)0.0f;
-                *reinterpret_cast<bf16x4 *>(&tile[pos_of(p) * CSTRIDE + 12 + part * 4]) = zz;
+                *reinterpret_cast<bf16x4 *>(&tile[pos_of(p) * CSF + 12 + part * 4]) = zz;
             }
             const float e0[4] = { v0.x, v0.y, v0.z, v0.w }, e1[4] = { v1.x, v1.y, v1.z, v1.w };
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = 4 * q0 + j, c = e / P, p = e - c * P;
-                tile[pos_of(p) * CSTRIDE + c] = (bf16)e0[j];
+                tile[pos_of(p) * CSF + c] = (bf16)e0[j];
             }
             if (q1 < 12 * P / 4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = 4 * q1 + j, c = e / P, p = e - c * P;
-                    tile[pos_of(p) * CSTRIDE + c] = (bf16)e1[j];
+                    tile[pos_of(p) * CSF + c] = (bf16)e1[j];
                 }
             }
         }
@@ -425,8 +453,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
             float *const rs = keep ? sv.rstd + (size_t)n * 4 : nullptr;
             conv_ln_relu<32, 32, 1, 5, false, false, true>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0, LayerSave{ xh0, ac0, rs });
             conv_ln_relu<32, 64, 1, 10, false, false, true>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1, LayerSave{ xh1, ac1, keep ? rs + 1 : nullptr });
+#if POL_ROWTILES
+            conv_ln_relu<64, 128, 2, 10, false, false, true>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2, LayerSave{ xh2, ac2, keep ? rs + 2 : nullptr });
+            conv_ln_relu<128, 128, 2, 10, false, true, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3, LayerSave{ xh3, nullptr, keep ? rs + 3 : nullptr });
+#else
             conv_ln_relu<64, 128, 4, 5, false, false, true>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2, LayerSave{ xh2, ac2, keep ? rs + 2 : nullptr });
             conv_ln_relu<128, 128, 4, 5, false, true, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3, LayerSave{ xh3, nullptr, keep ? rs + 3 : nullptr });
+#endif
         } else {
         conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
 #ifdef POL_CONV2_2x5
@@ -434,14 +467,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
 #else
         conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
 #endif
+#if POL_ROWTILES
+        conv_ln_relu<64, 128, 2, 10, false, false>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2);
+        conv_ln_relu<128, 128, 2, 10, false, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3);
+#else
         conv_ln_relu<64, 128, 4, 5, false, false>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2);
         conv_ln_relu<128, 128, 4, 5, false, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3);
+#endif
         }
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * P * 128);
         for (int q = tid; q < P * 16; q += THREADS) {
             const int p = q >> 4, part = q & 15;
-            dst[q] = *reinterpret_cast<const bf16x8 *>(&tile[pos_of(p) * CSTRIDE + part * 8]);
+            dst[q] = *reinterpret_cast<const bf16x8 *>(&tile[pos_of(p) * CSF + part * 8]);
         }
         if (BITS && tid < OBS_WORDS) obw[tid] = next_word;        // every read of obw happened before the first barrier of this sample
         __syncthreads();
