@@ -244,6 +244,17 @@ int  inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, fl
 int  inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, float *partial, int32_t slices,
                             int32_t elems_per_sample, int32_t N, void *stream);
 
+/* Host glue of the training path as kernels: the parameters change with every optimizer step, so the packed forms above are
+ * rebuilt per minibatch.
+ *   inv_policy_pack_conv  f32 [Cout][Cin][3][3] -> the bf16 A fragments of inv_policy_layer.w (transposed = 0; Cin padded to cin_pad)
+ *                         or of inv_policy_bwd_params.wt (transposed = 1: Wt[ci][8 - tap][co] = W[co][ci][tap]; cin_pad unused)
+ *   inv_policy_pack_ln    LayerNorm([C,10,15]) weight / bias f32 -> fp16 [150][C/4][weight x4 | bias x4] (inv_policy_layer.ln)
+ *   inv_policy_obs_to_x0  observations (f32 planes [N][12][10][15] or packed [N][57], obs_is_bits) -> bf16 channels-last
+ *                         [N][150][16], the layer-0 `x` operand of inv_policy_wgrad */
+int  inv_policy_pack_conv(const float *w, int32_t cout, int32_t cin, int32_t cin_pad, int32_t transposed, void *out_bf16, void *stream);
+int  inv_policy_pack_ln(const float *weight, const float *bias, int32_t cout, void *out_f16, void *stream);
+int  inv_policy_obs_to_x0(const void *obs, int32_t obs_is_bits, void *x0_bf16, int32_t N, void *stream);
+
 /* ---- the scalar tail of the PPO update ------------------------------------------------------
  * inv_ppo_loss: forward AND backward of the reference's minibatch loss (inversus_rl/ppo_agent.py:211-224)
  *     loss = mean(-min(ratio A, clamp(ratio, 1-c, 1+c) A)) + value_coef mean((v - R)^2) - entropy_coef mean(entropy)

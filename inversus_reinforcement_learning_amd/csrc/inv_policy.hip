@@ -40,7 +40,8 @@ namespace pol {
 constexpr int H = 10, W = 15, P = H * W;                 // 150 pixels
 constexpr int PW = W + 2, PH = H + 2, NPOS = PW * PH;    // 12 x 17 haloed tile, 204 positions
 constexpr int OBS_WORDS = (12 * W * H + 31) / 32;          // 57 u32 words of one packed observation
-constexpr int CSTRIDE = 136;                             // bf16 per position: 128 channels + 8 pad = 272 B (backward kernel)
+constexpr int CSTRIDE = 136;                             // bf16 per position: 128 channels + 8 pad = 272 B (POL_NO_ROWTILES builds)
+[[maybe_unused]] constexpr int kCStrideUnused = CSTRIDE;
 // Forward kernels (POL_ROWTILES): GEMM pixel tiles are BOARD ROWS (15 pixels + one dummy column that reads the right halo) on a
 // 288-B position stride.  ds_read_b128 is served in groups of 16 lanes that mix two channel groups (lanes 0-3, 12-15 of one,
 // 4-11 of the next): with consecutive positions 72 dwords (8 banks mod 64) apart and channel groups 4 dwords apart all sixteen
@@ -506,8 +507,12 @@ __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int l
     int tap0[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
+#if POL_ROWTILES
+        tap0[i] = ((n0 + i + 1) * PW + c16 + 1) * CSF - (PW + 1) * CSF + 8 * kg;       // tile = board row, column 15 = right halo (zeros)
+#else
         const int px = (n0 + i) * 16 + c16;
-        tap0[i] = pos_of(min(px, P - 1)) * CSTRIDE - (PW + 1) * CSTRIDE + 8 * kg;
+        tap0[i] = pos_of(min(px, P - 1)) * CSF - (PW + 1) * CSF + 8 * kg;
+#endif
     }
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi)
@@ -529,7 +534,7 @@ __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int l
         const int ksn = ks + 1 < KS ? ks + 1 : ks;
         const int ksa = ks + AD < KS ? ks + AD : KS - 1;
         const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
-        const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSTRIDE + kcn * 32;
+        const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSF + kcn * 32;
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
         POL_PIN();
@@ -557,28 +562,59 @@ template <int COUT, bool FROM_GLOBAL>
 __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf16 *xhat_n, float rstd, const bf16 *da_n, bf16 *dy_n, bf16 *dz_n,
                                                  bf16 *tile, float *red)
 {
-    constexpr int CH8 = COUT / 8, ITEMS = P * CH8;
+    // A thread owns the same NIT items (pixel, 8 channels) in both passes.  All of a pass's global loads are requested before
+    // the first one is used (one L2 / HBM round trip per pass instead of one per item), and pass B re-uses the x^ and LayerNorm
+    // weights that pass A fetched (80 registers at COUT = 128; the GEMM's registers are dead here) instead of loading them again.
+    constexpr int CH8 = COUT / 8, ITEMS = P * CH8, NIT = (ITEMS + THREADS - 1) / THREADS;
     const int tid = threadIdx.x;
+    bf16x8 xc[NIT];                                      // x^ of the thread's items
+    f16x8 gc[NIT];                                       // their 8 LayerNorm weights
     float s1 = 0.0f, s2 = 0.0f;
-    for (int q = tid; q < ITEMS; q += THREADS) {
-        const int p = q / CH8, part = q - p * CH8;
-        bf16 *tp = tile + pos_of(p) * CSTRIDE + part * 8;
-        const bf16x8 da = FROM_GLOBAL ? reinterpret_cast<const bf16x8 *>(da_n)[q] : *reinterpret_cast<const bf16x8 *>(tp);
-        const bf16x8 xh = reinterpret_cast<const bf16x8 *>(xhat_n)[q];
-        const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;       // (p * COUT + part * 8) * 2
-        const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
-        bf16x8 dy;
+    constexpr int CH = NIT < 5 ? NIT : 5;                // items in flight at once (12-16 registers each)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = (float)xh[e], g = (float)(e < 4 ? l0[e] : l1[e - 4]), b = (float)(e < 4 ? l0[4 + e] : l1[e]);
-            const float d = fmaf(x, g, b) > 0.0f ? (float)da[e] : 0.0f;
-            dy[e] = (bf16)d;
-            const float dxh = (float)dy[e] * g;          // from the ROUNDED dy: pass B recomputes exactly this value
-            s1 += dxh;
-            s2 += dxh * x;
+    for (int k0 = 0; k0 < NIT; k0 += CH) {
+        f16x8 l0[CH], l1[CH];
+        bf16x8 dag[FROM_GLOBAL ? CH : 1];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int k = k0 + j;
+            if (k < NIT) {
+                const int q = min(tid + k * THREADS, ITEMS - 1);     // clamped: the tail threads re-load the last item and discard it
+                xc[k] = reinterpret_cast<const bf16x8 *>(xhat_n)[q];
+                const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;   // (p * COUT + part * 8) * 2
+                l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+                l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+                if (FROM_GLOBAL) dag[j] = reinterpret_cast<const bf16x8 *>(da_n)[q];
+            }
         }
-        reinterpret_cast<bf16x8 *>(dy_n)[q] = dy;
-        *reinterpret_cast<bf16x8 *>(tp) = dy;
+        POL_PIN();
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int k = k0 + j, q = tid + k * THREADS;
+            if (k < NIT && q < ITEMS) {
+                const int p = q / CH8, part = q - p * CH8;
+                bf16 *tp = tile + pos_of(p) * CSF + part * 8;
+                const bf16x8 da = FROM_GLOBAL ? dag[FROM_GLOBAL ? j : 0] : *reinterpret_cast<const bf16x8 *>(tp);
+                const bf16x8 xh = xc[k];
+                bf16x8 dy;
+                f16x8 gk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16 gh = e < 4 ? l0[j][e] : l1[j][e - 4];
+                    gk[e] = gh;
+                    const float x = (float)xh[e], g = (float)gh, bb = (float)(e < 4 ? l0[j][4 + e] : l1[j][e]);
+                    const float d = fmaf(x, g, bb) > 0.0f ? (float)da[e] : 0.0f;
+                    dy[e] = (bf16)d;
+                    const float dxh = (float)dy[e] * g;  // from the ROUNDED dy: pass B recomputes exactly this value
+                    s1 += dxh;
+                    s2 += dxh * x;
+                }
+                gc[k] = gk;
+                reinterpret_cast<bf16x8 *>(dy_n)[q] = dy;
+                *reinterpret_cast<bf16x8 *>(tp) = dy;
+            }
+        }
+        POL_PIN();
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
@@ -590,21 +626,19 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
     for (int w = 0; w < WAVES; ++w) { S1 += red[w]; S2 += red[WAVES + w]; }
     const float inv_cnt = 1.0f / (float)(COUT * P);
     const float m1 = S1 * inv_cnt, m2 = S2 * inv_cnt;
-    for (int q = tid; q < ITEMS; q += THREADS) {         // same items as in pass A: this thread's own tile entries
-        const int p = q / CH8, part = q - p * CH8;
-        bf16 *tp = tile + pos_of(p) * CSTRIDE + part * 8;
-        const bf16x8 dy = *reinterpret_cast<const bf16x8 *>(tp);
-        const bf16x8 xh = reinterpret_cast<const bf16x8 *>(xhat_n)[q];
-        const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;
-        const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
-        bf16x8 dz;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float g = (float)(e < 4 ? l0[e] : l1[e - 4]);
-            dz[e] = (bf16)(rstd * ((float)dy[e] * g - m1 - (float)xh[e] * m2));
+    for (int k = 0; k < NIT; ++k) {                      // same items as in pass A: this thread's own tile entries
+        const int q = tid + k * THREADS;
+        if (q < ITEMS) {
+            const int p = q / CH8, part = q - p * CH8;
+            bf16 *tp = tile + pos_of(p) * CSF + part * 8;
+            const bf16x8 dy = *reinterpret_cast<const bf16x8 *>(tp);
+            bf16x8 dz;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dz[e] = (bf16)(rstd * ((float)dy[e] * (float)gc[k][e] - m1 - (float)xc[k][e] * m2));
+            reinterpret_cast<bf16x8 *>(dz_n)[q] = dz;
+            *reinterpret_cast<bf16x8 *>(tp) = dz;
         }
-        reinterpret_cast<bf16x8 *>(dz_n)[q] = dz;
-        *reinterpret_cast<bf16x8 *>(tp) = dz;
     }
     __syncthreads();                                 // dz tile complete (B operand of the transposed convolution); red[] reusable
 }
@@ -621,8 +655,12 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
         for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                const int px = min((n0 + i) * 16 + c16, P - 1);
-                const bf16x4 r = *reinterpret_cast<const bf16x4 *>(tile + pos_of(px) * CSTRIDE + (m0 + mi) * 16 + 4 * kg);
+#if POL_ROWTILES
+                const int posi = (n0 + i + 1) * PW + c16 + 1;                                // dummy column: halo, zeros
+#else
+                const int posi = pos_of(min((n0 + i) * 16 + c16, P - 1));
+#endif
+                const bf16x4 r = *reinterpret_cast<const bf16x4 *>(tile + posi * CSF + (m0 + mi) * 16 + 4 * kg);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[mi][i][e] += (float)r[e];
             }
@@ -632,12 +670,19 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
+#if POL_ROWTILES
+            const bool pv = c16 < W;
+            const int posi = (n0 + i + 1) * PW + c16 + 1;
+#else
             const int px = (n0 + i) * 16 + c16;
-            if (px < P) {
+            const bool pv = px < P;
+            const int posi = pos_of(min(px, P - 1));
+#endif
+            if (pv) {
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[mi][i][e];
-                *reinterpret_cast<bf16x4 *>(tile + pos_of(px) * CSTRIDE + (m0 + mi) * 16 + 4 * kg) = o;
+                *reinterpret_cast<bf16x4 *>(tile + posi * CSF + (m0 + mi) * 16 + 4 * kg) = o;
             }
         }
     __syncthreads();
@@ -646,11 +691,11 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
 __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_params prm, inv_policy_saved sv, const bf16 *__restrict__ dfeat,
                                                                    inv_policy_grads gr, int N)
 {
-    __shared__ __attribute__((aligned(16))) bf16 tile[NPOS * CSTRIDE];
+    __shared__ __attribute__((aligned(16))) bf16 tile[NPOSF * CSF];
     __shared__ float red[2 * WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
-    for (int i = tid; i < NPOS * CSTRIDE / 8; i += THREADS) {     // halo stays zero for the life of the block
+    for (int i = tid; i < NPOSF * CSF / 8; i += THREADS) {     // halo stays zero for the life of the block
         bf16x8 z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
@@ -664,7 +709,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         const float4 rs = *reinterpret_cast<const float4 *>(sv.rstd + (size_t)n * 4);
         ln_relu_bwd_rows<128, true>(prm.ln[3], reinterpret_cast<const bf16 *>(sv.xhat[3]) + sn * 128, rs.w, dfeat + sn * 128,
                                     reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red);
+#if POL_ROWTILES
+        conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0);
+#else
         conv_t_to_tile<128, 128, 4, 5, true>(prm.wt[2], tile, lane_i, (wave & 1) * 4, (wave >> 1) * 5);
+#endif
         ln_relu_bwd_rows<128, false>(prm.ln[2], reinterpret_cast<const bf16 *>(sv.xhat[2]) + sn * 128, rs.z, nullptr,
                                      reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128, tile, red);
         conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0);
@@ -886,6 +935,66 @@ __global__ __launch_bounds__(256) void k_policy_param_grads(const bf16 *__restri
     *reinterpret_cast<float4 *>(o + stride + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Host glue of the training path as kernels (the parameters change with every optimizer step, so they are re-packed per
+// minibatch: as torch index arithmetic this was ~60 small launches per minibatch).
+// pack_conv: f32 [Cout][Cin][3][3] -> bf16 A fragments [Cout'/16][9*CinP/32][64][8] (inversus_hip.h, inv_policy_layer.w).
+//   transposed = 0:  A[co][k = tap * CinP + ci] = W[co][ci][tap]                       (forward; Cout' = Cout, K side = Cin padded to CinP)
+//   transposed = 1:  A[ci][k = tap * Cout + co] = W[co][ci][8 - tap]                   (data gradient; Cout' = Cin, K side = Cout)
+__global__ __launch_bounds__(256) void k_pack_conv(const float *__restrict__ w, int cout, int cin, int cinp, int transposed, bf16 *__restrict__ out)
+{
+    const int m_rows = transposed ? cin : cout, kc = transposed ? cout : cinp, K = 9 * kc;
+    const long long total = (long long)m_rows * K;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    const long long frag = e >> 9;                                       // mt * (K / 32) + ks
+    const int ksn = K / 32, ks = (int)(frag % ksn), mt = (int)(frag / ksn);
+    const int row = 16 * mt + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+    const int tap = k / kc, c = k - tap * kc;
+    float v = 0.0f;
+    if (!transposed) { if (c < cin) v = w[((size_t)row * cin + c) * 9 + tap]; }
+    else v = w[((size_t)c * cin + row) * 9 + (8 - tap)];
+    out[e] = (bf16)v;
+}
+
+// pack_ln: LayerNorm([C,10,15]) weight / bias f32 -> fp16 [150][C/4][weight x4 | bias x4]
+__global__ __launch_bounds__(256) void k_pack_ln(const float *__restrict__ w, const float *__restrict__ b, int cout, _Float16 *__restrict__ out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;                        // one (pixel, channel)
+    if (e >= P * cout) return;
+    const int p = e / cout, c = e - p * cout;
+    _Float16 *o = out + ((size_t)p * cout + (c & ~3)) * 2 + (c & 3);
+    o[0] = (_Float16)w[(size_t)c * P + p];
+    o[4] = (_Float16)b[(size_t)c * P + p];
+}
+
+// obs_to_x0: the observation as the weight-gradient kernel's layer-1 operand, bf16 channels-last [N][150][16] (12 planes + 4 zero channels),
+// from f32 planes [N][12][150] or from the packed bitstrings [N][57]
+__global__ __launch_bounds__(256) void k_obs_to_x0(const void *__restrict__ obs, int is_bits, bf16 *__restrict__ x0, int N)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;      // one (sample, pixel)
+    if (e >= (long long)N * P) return;
+    const int n = (int)(e / P), p = (int)(e - (long long)n * P);
+    bf16x8 lo, hi;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float v = 0.0f;
+        if (c < 12) {
+            if (is_bits) {
+                const int bit = c * P + p;
+                v = (float)((reinterpret_cast<const uint32_t *>(obs)[(size_t)n * OBS_WORDS + (bit >> 5)] >> (bit & 31)) & 1u);
+            } else {
+                v = reinterpret_cast<const float *>(obs)[((size_t)n * 12 + c) * P + p];
+            }
+        }
+        if (c < 8) lo[c] = (bf16)v; else hi[c - 8] = (bf16)v;
+    }
+    bf16x8 *dst = reinterpret_cast<bf16x8 *>(x0 + (size_t)e * 16);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
 }  // namespace pol
 
 #ifdef INV_POLICY_STAMPS
@@ -910,6 +1019,36 @@ static int launch_status(const char *what)
 {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? INV_OK : inv_fail(INV_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+
+extern "C" int inv_policy_pack_conv(const float *w, int32_t cout, int32_t cin, int32_t cin_pad, int32_t transposed, void *out_bf16, void *stream)
+{
+    const int kc = transposed ? cout : cin_pad, rows = transposed ? cin : cout;
+    if (!w || !out_bf16 || cout < 1 || cin < 1 || cin_pad < cin || (rows & 15) || ((9 * kc) & 31))
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_pack_conv: NULL tensor or shapes that do not tile into 16 x 32 fragments");
+    const long long total = (long long)rows * 9 * kc;
+    hipLaunchKernelGGL(pol::k_pack_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (int)cout, (int)cin, (int)cin_pad,
+                       (int)(transposed != 0), reinterpret_cast<pol::bf16 *>(out_bf16));
+    return launch_status("inv_policy_pack_conv");
+}
+
+extern "C" int inv_policy_pack_ln(const float *weight, const float *bias, int32_t cout, void *out_f16, void *stream)
+{
+    if (!weight || !bias || !out_f16 || cout < 4 || (cout & 3)) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_pack_ln: NULL tensor or cout not a multiple of 4");
+    hipLaunchKernelGGL(pol::k_pack_ln, dim3((pol::P * cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, bias, (int)cout,
+                       reinterpret_cast<_Float16 *>(out_f16));
+    return launch_status("inv_policy_pack_ln");
+}
+
+extern "C" int inv_policy_obs_to_x0(const void *obs, int32_t obs_is_bits, void *x0_bf16, int32_t N, void *stream)
+{
+    if (!obs || !x0_bf16 || N < 0) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_obs_to_x0: NULL tensor or N < 0");
+    if (N == 0) return INV_OK;
+    const long long total = (long long)N * pol::P;
+    hipLaunchKernelGGL(pol::k_obs_to_x0, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, (int)(obs_is_bits != 0),
+                       reinterpret_cast<pol::bf16 *>(x0_bf16), (int)N);
+    return launch_status("inv_policy_obs_to_x0");
 }
 
 static bool layers_ok(const inv_policy_params *params)

@@ -28,6 +28,33 @@ def _pack_conv(w, cin_pad):
     return wk.reshape(cout // 16, k // 32, 64, 8).contiguous().to(torch.bfloat16)
 
 
+def pack_conv(w, cin_pad, transposed=False):
+    """_pack_conv (transposed=False) or the data-gradient form Wt[ci][8 - tap][co] = W[co][ci][tap] (transposed=True) as ONE kernel
+    (inv_policy_pack_conv) instead of five torch index kernels; `w`: f32 [Cout, Cin, 3, 3] on the GPU."""
+    lib = L.load()
+    w = w.detach().float().contiguous()
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    rows, kc = (cin, cout) if transposed else (cout, int(cin_pad))
+    out = torch.empty((rows // 16, 9 * kc // 32, 64, 8), dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = lib.inv_policy_pack_conv(C.c_void_p(w.data_ptr()), cout, cin, int(cin_pad), int(bool(transposed)), C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    L.raise_for(rc, lib)
+    return out
+
+
+def pack_ln(weight, bias, cout):
+    """LayerNorm([C,10,15]) affine -> fp16 [150][C/4][weight x4 | bias x4] as one kernel (inv_policy_pack_ln)."""
+    lib = L.load()
+    w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+    out = torch.empty((150, cout // 4, 8), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = lib.inv_policy_pack_ln(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), int(cout), C.c_void_p(out.data_ptr()),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    L.raise_for(rc, lib)
+    return out
+
+
 class FusedPolicy:
     """Callable like the module in eval mode: (grid f32 [B,12,10,15] or packed int32 [B,57], extra f32 [B,4]) -> (logits, value)."""
 
@@ -52,12 +79,10 @@ class FusedPolicy:
         params = L.InvPolicyParams()
         for i, (conv, norm) in enumerate(((p.conv1, p.norm1), (p.conv2, p.norm2), (p.conv3, p.norm3), (p.conv4, p.norm4))):
             cout = conv.out_channels
-            w = _pack_conv(conv.weight.detach().float(), _CIN_PAD[i])
+            w = pack_conv(conv.weight, _CIN_PAD[i])
             b = conv.bias.detach().float().contiguous()
             # LayerNorm affine, [pixel][channel/4][weight x4 | bias x4] in fp16: one 16-byte load per accumulator tile
-            lnw = norm.weight.detach().float().reshape(cout, 150).t().reshape(150, cout // 4, 4)
-            lnb = norm.bias.detach().float().reshape(cout, 150).t().reshape(150, cout // 4, 4)
-            ln = torch.cat([lnw, lnb], dim=2).contiguous().to(torch.float16)
+            ln = pack_ln(norm.weight, norm.bias, cout)
             self._keep += [w, b, ln]
             params.layer[i] = L.InvPolicyLayer(w.data_ptr(), b.data_ptr(), ln.data_ptr())
         self.params = params

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from .device_env import unpack_obs
-from .fused_policy import _CIN_PAD, _pack_conv
+from .fused_policy import _CIN_PAD, _pack_conv, pack_conv, pack_ln
 
 _COUT = (32, 64, 128, 128)
 _CIN = (12, 32, 64, 128)
@@ -88,9 +88,9 @@ class _TrunkTrainFn(torch.autograd.Function):
         lns = []
         for i in range(4):
             w, b, g, e = params[4 * i:4 * i + 4]
-            wp = _pack_conv(w.detach().float(), _CIN_PAD[i])
+            wp = pack_conv(w, _CIN_PAD[i])
             bp = b.detach().float().contiguous()
-            ln = _pack_ln(g, e, _COUT[i])
+            ln = pack_ln(g, e, _COUT[i])
             keep += [wp, bp, ln]
             lns.append(ln)
             fwd.layer[i] = L.InvPolicyLayer(wp.data_ptr(), bp.data_ptr(), ln.data_ptr())
@@ -124,8 +124,7 @@ class _TrunkTrainFn(torch.autograd.Function):
         dz = [torch.empty_like(t) for t in xhat]
         bp, keep = L.InvPolicyBwdParams(), []
         for i in range(1, 4):                       # Wt[ci][8 - tap][co] = W[co][ci][tap], packed as a conv with Cin = Cout_i
-            wt = ws[i].detach().float().flip(2, 3).permute(1, 0, 2, 3).contiguous()
-            pk = _pack_conv(wt, _COUT[i])
+            pk = pack_conv(ws[i], _COUT[i], transposed=True)
             keep.append(pk)
             bp.wt[i - 1] = pk.data_ptr()
         for i in range(4):
@@ -142,9 +141,10 @@ class _TrunkTrainFn(torch.autograd.Function):
             rc = lib.inv_policy_trunk_bwd(C.byref(bp), C.byref(saved), _ptr(dfeat), C.byref(grads), n,
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.raise_for(rc, lib)
-        planes = unpack_obs(obs) if ctx.bits else obs
-        x0 = torch.zeros((n, 150, 16), dtype=torch.bfloat16, device=dev)              # channels-last layer-1 input, 12 -> 16 channels
-        x0[:, :, :12] = planes.reshape(n, 12, 150).permute(0, 2, 1)
+        x0 = torch.empty((n, 150, 16), dtype=torch.bfloat16, device=dev)              # channels-last layer-1 input, 12 -> 16 channels
+        with torch.cuda.device(dev):
+            rc = lib.inv_policy_obs_to_x0(_ptr(obs), 1 if ctx.bits else 0, _ptr(x0), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.raise_for(rc, lib)
         out = [None]
         for i in range(4):
             c = _COUT[i]

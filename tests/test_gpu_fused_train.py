@@ -183,3 +183,34 @@ def test_rollout_forward_uses_the_updates_numerics_when_the_update_is_fused():
         lo_i, _ = FusedPolicy(pol)(grid, extra)                  # inference epilogue: close, but not the same numbers
         lp_i = torch.distributions.Categorical(logits=lo_i.float(), validate_args=False).log_prob(acts)
         assert 5e-4 < float((lp_i - old_lp).abs().max()) < 0.1
+
+
+def test_pack_kernels_equal_the_torch_index_arithmetic():
+    """inv_policy_pack_conv / pack_ln / obs_to_x0 against the torch formulations they replace (bit-equal: pure data movement + one rounding)."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import unpack_obs
+    from inversus_reinforcement_learning_amd.fused_policy import _pack_conv, pack_conv, pack_ln
+    from inversus_reinforcement_learning_amd.fused_train import _pack_ln
+    from inversus_reinforcement_learning_amd import _lib as L
+    import ctypes as C
+    torch.manual_seed(3)
+    for cout, cin, pad in ((32, 12, 32), (64, 32, 32), (128, 64, 64), (128, 128, 128)):
+        w = torch.randn(cout, cin, 3, 3, device="cuda")
+        assert torch.equal(pack_conv(w, pad), _pack_conv(w, pad))
+        if cin % 16 == 0:
+            wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+            assert torch.equal(pack_conv(w, cout, transposed=True), _pack_conv(wt, cout))
+        g, b = torch.randn(cout, 10, 15, device="cuda"), torch.randn(cout, 10, 15, device="cuda")
+        assert torch.equal(pack_ln(g, b, cout), _pack_ln(g, b, cout))
+    n = 77
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, 57), dtype=torch.int32, device="cuda")
+    bits[:, 56] &= 0xFF
+    planes = unpack_obs(bits)
+    want = torch.zeros((n, 150, 16), dtype=torch.bfloat16, device="cuda")
+    want[:, :, :12] = planes.reshape(n, 12, 150).permute(0, 2, 1)
+    lib = L.load()
+    for src, is_bits in ((bits, 1), (planes, 0)):
+        x0 = torch.empty_like(want)
+        L.raise_for(lib.inv_policy_obs_to_x0(C.c_void_p(src.data_ptr()), is_bits, C.c_void_p(x0.data_ptr()), n,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), lib)
+        assert torch.equal(x0, want)
