@@ -260,7 +260,9 @@ def side_measurements(torch, np, n):
         opp = FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval())
         for packed, key in ((True, "selfplay_collector_env_steps_per_s"), (False, "selfplay_collector_f32_obs_env_steps_per_s")):
             col = RolloutCollector(b, agent, opp, packed_obs=packed)
-            col.collect(2); agent.reset_buffers(); torch.cuda.synchronize()
+            # warm-up with the SAME number of steps: the rollout buffer keeps every step's observations alive, so a shorter
+            # warm-up leaves hipMalloc calls of 118 MB blocks inside the timed region (the f32 variant read 1.3 M instead of 4.8 M)
+            col.collect(8); agent.reset_buffers(); torch.cuda.synchronize()
             t0 = time.perf_counter(); col.collect(8); torch.cuda.synchronize()
             res[key] = round(8 * n / (time.perf_counter() - t0))
             agent.reset_buffers()

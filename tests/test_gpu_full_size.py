@@ -159,3 +159,42 @@ def test_adversarial_32x32_trace_reaches_14_live_bullets():
         mx = max(mx, int(o["nbullets"].max()))
     assert mx == 14, mx
     b.check()                                                            # no overflow flag
+
+
+def test_c4_total_size_131072_envs_equals_eight_shards_of_16384():
+    """BASELINE config C4's env path at its TOTAL size on one GPU: one batch of 131 072 self-play envs (what the 8-GPU run
+    holds in total) equals eight shards of 16 384 with env_offset = 16384 * rank (what each rank holds) -- packed P1 / P2
+    observations, rewards, dones and final state of every env -- and four 64-env blocks equal the oracle.  The 8-GPU job
+    itself needs the driver's node; its only collective is the gradient all-reduce (tests/test_policy_dist_cpu.py)."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from oracle import oracle as orc
+    n_total, n_shard, T = 131072, 16384, 12
+    base = 5_000_000
+    g = torch.Generator(device="cuda").manual_seed(8)
+    a1 = torch.randint(0, 13, (T, n_total), device="cuda", generator=g, dtype=torch.uint8)
+    a2 = torch.randint(0, 13, (T, n_total), device="cuda", generator=g, dtype=torch.uint8)
+    big = DeviceEnvBatch(n_total, opponent="selfplay", max_episode_steps=7)
+    big.seed(base + np.arange(n_total, dtype=np.int64)); big.reset()
+    rb = big.rollout(a1, a2, obs_p2=True, bits=True)
+    for rank in (0, 3, 7):
+        lo = rank * n_shard
+        sh = DeviceEnvBatch(n_shard, opponent="selfplay", max_episode_steps=7, env_offset=lo)
+        sh.seed(base + lo + np.arange(n_shard, dtype=np.int64)); sh.reset()
+        rs = sh.rollout(a1[:, lo:lo + n_shard].contiguous(), a2[:, lo:lo + n_shard].contiguous(), obs_p2=True, bits=True)
+        for k in ("obs", "obs_p2", "extra", "reward", "done", "info_flags", "episode_steps", "episode_return"):
+            assert torch.equal(getattr(rs, k), getattr(rb, k)[:, lo:lo + n_shard]), (rank, k)
+        ss, sb = sh.get_state(), big.get_state()
+        for k in ss:
+            assert bits_eq(ss[k], sb[k][lo:lo + n_shard]), (rank, k)
+    a1h, a2h = a1.cpu().numpy(), a2.cpu().numpy()
+    for off in (0, 40000, 99999, n_total - 64):
+        ob = orc.OracleBatch(64, max_episode_steps=7)
+        ob.seed_reset(base + off + np.arange(64, dtype=np.int64))
+        for t in range(T):
+            o_obs, _, o_r32, _, o_done, _ = ob.step(a1h[t, off:off + 64], a2h[t, off:off + 64])
+            assert bits_eq(rb.reward[t, off:off + 64].cpu().numpy(), o_r32) and np.array_equal(rb.done[t, off:off + 64].cpu().numpy(), o_done), (off, t)
+            want = np.packbits(o_obs.reshape(64, -1) != 0, axis=1, bitorder="little")
+            want = np.pad(want, ((0, 0), (0, 57 * 4 - want.shape[1]))).view(np.uint32)
+            assert np.array_equal(rb.obs[t, off:off + 64].cpu().numpy().view(np.uint32), want), (off, t)
+    big.check()
