@@ -257,7 +257,7 @@ def side_measurements(torch, np, n):
         b = DeviceEnvBatch(n, opponent="selfplay")
         b.seed(np.arange(n, dtype=np.int64)); b.reset()
         agent = PPOAgent(pol, fused_act=True)
-        opp = FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval())
+        opp = FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval(), actor_only=True)       # as training.py builds it
         for packed, key in ((True, "selfplay_collector_env_steps_per_s"), (False, "selfplay_collector_f32_obs_env_steps_per_s")):
             col = RolloutCollector(b, agent, opp, packed_obs=packed)
             # warm-up with the SAME number of steps: the rollout buffer keeps every step's observations alive, so a shorter
@@ -279,7 +279,7 @@ def side_measurements(torch, np, n):
         b = DeviceEnvBatch(n, opponent="selfplay")
         b.seed(np.arange(n, dtype=np.int64)); b.reset()
         agent = PPOAgent(InversusCNNPolicy(12, H, W, 4), fused_act=True, fused_update=True, batch_size=n, epochs=1)
-        col = RolloutCollector(b, agent, FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval()))
+        col = RolloutCollector(b, agent, FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval(), actor_only=True))
         T = 8
         col.collect(T); agent.update()                                     # warm-up (allocator, GEMM heuristics)
         torch.cuda.synchronize(); t0 = time.perf_counter()

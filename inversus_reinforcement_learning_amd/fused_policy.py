@@ -58,12 +58,15 @@ def pack_ln(weight, bias, cout):
 class FusedPolicy:
     """Callable like the module in eval mode: (grid f32 [B,12,10,15] or packed int32 [B,57], extra f32 [B,4]) -> (logits, value)."""
 
-    def __init__(self, policy, train_numerics=False):
-        """train_numerics: run the trunk with the numerics of the fused UPDATE's forward (x^ rounded to bf16 before the
+    def __init__(self, policy, train_numerics=False, actor_only=False):
+        """actor_only: compute the action logits only (value = None) -- the frozen self-play opponent never needs its critic, and
+        without it the first Linear of the heads is a [256 x 19204] GEMM instead of [512 x 19204] (half of the heads' time).
+        train_numerics: run the trunk with the numerics of the fused UPDATE's forward (x^ rounded to bf16 before the
         LayerNorm affine, csrc/inv_policy.hip SAVE path) instead of the slightly more accurate inference epilogue, so that
         log-probs / values stored during rollouts are what the update's first forward recomputes (PPO ratio = 1)."""
         self.policy = policy
         self.train_numerics = bool(train_numerics)
+        self.actor_only = bool(actor_only)
         self.lib = L.load()
         self.refresh()
 
@@ -88,11 +91,12 @@ class FusedPolicy:
         self.params = params
         # heads: first Linear of actor and critic concatenated; columns permuted from the module's
         # flatten order (c*150 + pixel) to the kernel's channels-last order (pixel*128 + c)
-        w1 = torch.cat([p.fc_actor[0].weight, p.fc_critic[0].weight]).detach().float()      # [512, 19204]
+        firsts = [p.fc_actor[0]] if self.actor_only else [p.fc_actor[0], p.fc_critic[0]]
+        w1 = torch.cat([m.weight for m in firsts]).detach().float()                         # [512 (256: actor only), 19204]
         hid = w1.shape[0]
         self.w1_feat = w1[:, :19200].reshape(hid, 128, 150).permute(0, 2, 1).reshape(hid, 19200).contiguous().to(torch.bfloat16)
         self.w1_extra = w1[:, 19200:].contiguous()
-        self.b1 = torch.cat([p.fc_actor[0].bias, p.fc_critic[0].bias]).detach().float()
+        self.b1 = torch.cat([m.bias for m in firsts]).detach().float()
         self.hidden = p.fc_actor[0].out_features
 
     @torch.no_grad()
@@ -122,7 +126,8 @@ class FusedPolicy:
         feat = self.features(grid)
         h = (feat @ self.w1_feat.t()).float() + extra.float() @ self.w1_extra.t() + self.b1
         h = torch.relu(h)
-        ha, hc = h[:, :self.hidden], h[:, self.hidden:]
-        logits = p.fc_actor[4](torch.relu(p.fc_actor[2](ha)))
-        value = p.fc_critic[4](torch.relu(p.fc_critic[2](hc)))
+        logits = p.fc_actor[4](torch.relu(p.fc_actor[2](h[:, :self.hidden])))
+        if self.actor_only:
+            return logits, None
+        value = p.fc_critic[4](torch.relu(p.fc_critic[2](h[:, self.hidden:])))
         return logits, value

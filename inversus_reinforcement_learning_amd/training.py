@@ -168,7 +168,7 @@ def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, w
     opp_module = opponent
     if opponent is not None and agent.fused is not None:
         from .fused_policy import FusedPolicy
-        opponent = FusedPolicy(opp_module)                          # the frozen opponent acts through the fused trunk too
+        opponent = FusedPolicy(opp_module, actor_only=True)         # the frozen opponent acts through the fused trunk too; no critic
     collector = RolloutCollector(batch, agent, opponent)
     logger = TrainingLogger(log_dir) if (log_dir and rank == 0) else None
 

@@ -94,3 +94,19 @@ def test_refresh_tracks_weight_updates():
     with torch.no_grad():
         ref, _ = pol(grid, extra)
     assert float((l1 - ref).abs().max()) < 0.05 and not torch.equal(l0, l1)
+
+
+def test_actor_only_opponent_gives_the_same_logits():
+    """FusedPolicy(actor_only=True) -- the frozen self-play opponent -- skips the critic: same logits, value None."""
+    import torch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    torch.manual_seed(1)
+    pol = InversusCNNPolicy(12, 10, 15, 4).cuda().eval()
+    g = (torch.rand(300, 12, 10, 15, device="cuda") < 0.2).float()
+    x = torch.rand(300, 4, device="cuda")
+    full, act = FusedPolicy(pol), FusedPolicy(pol, actor_only=True)
+    lf, vf = full(g, x)
+    la, va = act(g, x)
+    assert va is None and vf.shape == (300, 1) and act.w1_feat.shape == (256, 19200)
+    assert float((lf - la).abs().max()) < 2e-3          # the same trunk features; the first Linear runs as a narrower GEMM

@@ -13,7 +13,7 @@ n = 16384
 torch.manual_seed(0)
 b = DeviceEnvBatch(n, opponent="selfplay"); b.seed(np.arange(n, dtype=np.int64)); b.reset()
 agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), fused_act=True)
-opp = FusedPolicy(InversusCNNPolicy(12, 10, 15, 4).cuda().eval())
+opp = FusedPolicy(InversusCNNPolicy(12, 10, 15, 4).cuda().eval(), actor_only=len(sys.argv) < 2 or sys.argv[1] != 'full')
 res = {"packed": [], "f32": []}
 for rep in range(4):
     for packed in (True, False):
