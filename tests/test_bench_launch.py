@@ -48,6 +48,16 @@ def test_self_launched_two_ranks_share_the_gpu_over_gloo():
 
 
 @pytest.mark.gpu
+def test_self_launched_four_ranks_share_the_gpu_over_gloo():
+    """Four ranks (env shards 0..3 of 16 384 envs each) on the one GPU: the rank arithmetic beyond two ranks."""
+    res = parse_line(run_bench("--gpus", "4", "--backend", "gloo", "--share-device", "--steps", "30", "--warmup", "5",
+                               "--repeats", "2", "--no-cpu-baseline", "--no-extras"))
+    assert res["n_gpus"] == 4 and len(res["roofline"]["kernel_ms_per_rank"]) == 4
+    assert res["config"]["sharding"].startswith("env-shards x4")
+    assert abs(res["value"] - 4 * 16384 * 30 / (res["ms_per_step"] * 30e-3)) < 1e-3 * res["value"]
+
+
+@pytest.mark.gpu
 def test_external_launcher_is_respected():
     """Under torch.distributed.run (the driver's N > 1 form) bench.py must NOT spawn again."""
     env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
