@@ -213,6 +213,15 @@ int  inv_policy_trunk(const inv_policy_params *params, const float *obs, void *f
  * 228 B instead of 7 200 B per sample, the next sample's words are fetched while the current one computes. */
 int  inv_policy_trunk_bits(const inv_policy_params *params, const uint32_t *bits, void *feat_bf16, int32_t N, void *stream);
 
+/* The trunk for boards whose activations do not fit LDS (BASELINE config C5: 32 x 32), same parameter packing with H*W pixels
+ * (ln: fp16 [H*W][Cout/4][8]); obs: f32 [N][12][H][W] or packed uint32_t [N][ceil(12*H*W/32)] (obs_is_bits); feat: bf16
+ * [N][H*W][128].  Per sample and layer the board is processed in bands of 4 rows; the layers' pre-norm outputs stream through
+ * `scratch` (inv_policy_trunk_banded_scratch_bytes(H, W) bytes of device memory, reused by every launch on a stream; 0 =
+ * board not supported).  Built for 32 x 32. */
+int64_t inv_policy_trunk_banded_scratch_bytes(int32_t height, int32_t width);
+int  inv_policy_trunk_banded(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, int32_t height, int32_t width,
+                             void *feat_bf16, void *scratch, int64_t scratch_bytes, int32_t N, void *stream);
+
 /* ---- the same trunk for the PPO update: forward that keeps what the backward needs, and the
  * backward of LayerNorm/ReLU + the data gradient of the convolutions (ppo_agent.py:219-224 runs autograd over
  * policies.py:91-99).  All tensors bf16 channels-last [N][150][C_l], C = 32, 64, 128, 128:
@@ -248,11 +257,11 @@ int  inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, float *p
  * rebuilt per minibatch.
  *   inv_policy_pack_conv  f32 [Cout][Cin][3][3] -> the bf16 A fragments of inv_policy_layer.w (transposed = 0; Cin padded to cin_pad)
  *                         or of inv_policy_bwd_params.wt (transposed = 1: Wt[ci][8 - tap][co] = W[co][ci][tap]; cin_pad unused)
- *   inv_policy_pack_ln    LayerNorm([C,10,15]) weight / bias f32 -> fp16 [150][C/4][weight x4 | bias x4] (inv_policy_layer.ln)
+ *   inv_policy_pack_ln    LayerNorm([C,H,W]) weight / bias f32 -> fp16 [H*W][C/4][weight x4 | bias x4] (inv_policy_layer.ln); pixels = H*W
  *   inv_policy_obs_to_x0  observations (f32 planes [N][12][10][15] or packed [N][57], obs_is_bits) -> bf16 channels-last
  *                         [N][150][16], the layer-0 `x` operand of inv_policy_wgrad */
 int  inv_policy_pack_conv(const float *w, int32_t cout, int32_t cin, int32_t cin_pad, int32_t transposed, void *out_bf16, void *stream);
-int  inv_policy_pack_ln(const float *weight, const float *bias, int32_t cout, void *out_f16, void *stream);
+int  inv_policy_pack_ln(const float *weight, const float *bias, int32_t cout, int32_t pixels, void *out_f16, void *stream);
 int  inv_policy_obs_to_x0(const void *obs, int32_t obs_is_bits, void *x0_bf16, int32_t N, void *stream);
 
 /* ---- the scalar tail of the PPO update ------------------------------------------------------

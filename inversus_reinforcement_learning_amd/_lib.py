@@ -93,7 +93,9 @@ SIGNATURES = {
     "inv_policy_wgrad": (C.c_int, [C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_param_grads": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V]),
     "inv_policy_pack_conv": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V]),
-    "inv_policy_pack_ln": (C.c_int, [_V, _V, C.c_int32, _V, _V]),
+    "inv_policy_pack_ln": (C.c_int, [_V, _V, C.c_int32, C.c_int32, _V, _V]),
+    "inv_policy_trunk_banded_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "inv_policy_trunk_banded": (C.c_int, [P(InvPolicyParams), _V, C.c_int32, C.c_int32, C.c_int32, _V, _V, C.c_int64, C.c_int32, _V]),
     "inv_policy_obs_to_x0": (C.c_int, [_V, C.c_int32, _V, C.c_int32, _V]),
     "inv_ppo_loss_blocks": (C.c_int32, [C.c_int32]),
     "inv_ppo_loss": (C.c_int, [_V, _V, _V, _V, _V, _V, C.c_int32, C.c_float, C.c_float, C.c_float, _V, _V, _V, _V]),

@@ -490,6 +490,297 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Board-generic trunk for boards whose activations do not fit LDS ("banded"; SURVEY.md 8f row N1 for BASELINE config C5:
+// 32 x 32 is 262 KB of bf16 activations per layer and sample).  Per sample and layer the board is processed in BANDS of R
+// rows: the band's input (R + 2 rows with halo) is built in the LDS tile -- layer 1 from the observation, later layers from the
+// previous layer's PRE-norm output z (bf16 channels-last in a per-workgroup scratch that stays in L2 / Infinity Cache) with
+// LayerNorm + affine + ReLU applied on the way in, which is possible because a layer's statistics are complete before the
+// next layer starts -- then the same implicit GEMM as above runs on the band (tiles of 16 pixels = pieces of board rows: no
+// dummy columns, conflict-free on the 288-B stride), the statistics are accumulated from the f32 accumulators, and z goes back
+// to the scratch through the tile (whole 2*COUT-byte rows).  A last pass normalises z4 into the feature vector.
+// z is rounded to bf16 BEFORE its LayerNorm (the 15 x 10 kernel normalises the f32 accumulator): one more rounding of the same
+// size as the bf16 activations' own; tests bound the features against the f32 module.
+template <int HB, int WB, int R>
+struct BandGeo {
+    static constexpr int P = HB * WB, PWB = WB + 2, TR = R + 2, NPOSB = TR * PWB + 1, NB = HB / R;
+    static constexpr int TPR = WB / 16, NT = R * TPR;                 // 16-pixel tiles per board row / per band
+    static constexpr int OWB = (12 * P + 31) / 32;
+    static_assert(WB % 16 == 0 && HB % R == 0 && NT % 2 == 0 && NT <= 10, "band geometry");
+};
+
+// x^ w + b, ReLU, for 8 channels; l0 / l1: {weight x4 | bias x4} of channels 0..3 / 4..7
+__device__ __forceinline__ bf16x8 ln_relu8(const bf16x8 z, const f16x8 l0, const f16x8 l1, float rstd, float shift)
+{
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = (bf16)fmaxf(fmaf(fmaf((float)z[e], rstd, shift), (float)l0[e], (float)l0[4 + e]), 0.0f);
+        o[4 + e] = (bf16)fmaxf(fmaf(fmaf((float)z[4 + e], rstd, shift), (float)l1[e], (float)l1[4 + e]), 0.0f);
+    }
+    return o;
+}
+
+// layers 2..4: tile <- relu(LN(z_prev)) for the band's R + 2 rows, zeros outside the board
+template <class G, int R, int CPREV>
+__device__ __forceinline__ void band_load_norm(bf16 *tile, const bf16 *__restrict__ zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band)
+{
+    constexpr int C8 = CPREV / 8, ITEMS = G::TR * G::PWB * C8, NIT = (ITEMS + THREADS - 1) / THREADS, CH = 4;
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int k0 = 0; k0 < NIT; k0 += CH) {
+        bf16x8 z[CH];
+        f16x8 l0[CH], l1[CH];
+        int dsto[CH];
+        bool in[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int q = tid + (k0 + j) * THREADS;
+            const int pos = q / C8, part = q - pos * C8, tr = pos / G::PWB, tc = pos - tr * G::PWB;
+            const int y = band * R + tr - 1, x = tc - 1;
+            in[j] = q < ITEMS && (unsigned)y < (unsigned)(G::P / (G::PWB - 2)) && (unsigned)x < (unsigned)(G::PWB - 2);
+            dsto[j] = q < ITEMS ? pos * CSF + part * 8 : -1;
+            const int p = in[j] ? y * (G::PWB - 2) + x : 0;
+            const size_t o = (size_t)p * CPREV + part * 8;
+            z[j] = *reinterpret_cast<const bf16x8 *>(zprev + o);
+            const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_prev) + o * 2;
+            l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+            l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+        }
+        POL_PIN();
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (dsto[j] >= 0) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)0.0f;
+                if (in[j]) o = ln_relu8(z[j], l0[j], l1[j], rstd, shift);
+                *reinterpret_cast<bf16x8 *>(tile + dsto[j]) = o;
+            }
+        }
+    }
+}
+
+// layer 1: tile <- the observation's 12 planes (+ 20 zero channels) for the band's R + 2 rows
+template <class G, int R, bool BITS>
+__device__ __forceinline__ void band_load_obs(bf16 *tile, const uint32_t *obw, const float *__restrict__ planes, int band)
+{
+    constexpr int WBc = G::PWB - 2, HBc = G::P / WBc;
+    for (int z = threadIdx.x; z < G::TR * G::PWB * 8; z += THREADS) {       // one 8-byte quad (4 channels) per item
+        const int pos = z >> 3, part = z & 7, tr = pos / G::PWB, tc = pos - tr * G::PWB;
+        const int y = band * R + tr - 1, x = tc - 1;
+        uint32_t lo = 0u, hi = 0u;
+        if (part < 3 && (unsigned)y < (unsigned)HBc && (unsigned)x < (unsigned)WBc) {
+            const int p = y * WBc + x;
+            if (BITS) {
+                const int b0 = (4 * part) * G::P + p, b1 = b0 + G::P, b2 = b1 + G::P, b3 = b2 + G::P;
+                lo = (((obw[b0 >> 5] >> (b0 & 31)) & 1u) * 0x3F80u) | (((obw[b1 >> 5] >> (b1 & 31)) & 1u) * 0x3F800000u);
+                hi = (((obw[b2 >> 5] >> (b2 & 31)) & 1u) * 0x3F80u) | (((obw[b3 >> 5] >> (b3 & 31)) & 1u) * 0x3F800000u);
+            } else {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16)planes[(size_t)(4 * part + e) * G::P + p];
+                const uint2 u = __builtin_bit_cast(uint2, v);
+                lo = u.x; hi = u.y;
+            }
+        }
+        *reinterpret_cast<uint2 *>(tile + pos * CSF + part * 4) = make_uint2(lo, hi);
+    }
+}
+
+// conv3x3 on the band + bias (+ residual), statistics, z (bf16) back to the scratch through the tile
+template <class G, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL>
+__device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile, bf16 *__restrict__ zout, int band, int lane, int m0, int n0, float &s, float &ss)
+{
+    constexpr int KPT = CIN / 32, KS = 9 * KPT;
+    const int c16 = lane & 15, kg = lane >> 4;
+    int base[NW], tap0[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int t = n0 + i, rr = t / G::TPR, col0 = (t - rr * G::TPR) * 16;
+        base[i] = ((rr + 1) * G::PWB + col0 + c16 + 1) * CSF;
+        tap0[i] = base[i] - (G::PWB + 1) * CSF + 8 * kg;
+    }
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const float4 bq = *reinterpret_cast<const float4 *>(lp.bias + (m0 + mi) * 16 + 4 * kg);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { acc[mi][i][0] = bq.x; acc[mi][i][1] = bq.y; acc[mi][i][2] = bq.z; acc[mi][i][3] = bq.w; }
+    }
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
+    constexpr int AD = 3;
+    bf16x8 a[AD + 1][MW], b[NW];
+#pragma unroll
+    for (int d = 0; d < AD; ++d)
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) a[d][mi] = wp[((size_t)mi * KS + (d < KS ? d : KS - 1)) * 64];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int ksn = ks + 1 < KS ? ks + 1 : ks;
+        const int ksa = ks + AD < KS ? ks + AD : KS - 1;
+        const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
+        const int off_n = ((tapn / 3) * G::PWB + (tapn % 3)) * CSF + kcn * 32;
+#pragma unroll
+        for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
+        POL_PIN();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi)
+                acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
+            b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
+            POL_PIN();
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int ch0 = (m0 + mi) * 16 + 4 * kg;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            float x0 = acc[mi][i][0], x1 = acc[mi][i][1], x2 = acc[mi][i][2], x3 = acc[mi][i][3];
+            if (RESIDUAL) {
+                const bf16x4 rq = *reinterpret_cast<const bf16x4 *>(tile + base[i] + ch0);
+                x0 += (float)rq[0]; x1 += (float)rq[1]; x2 += (float)rq[2]; x3 += (float)rq[3];
+                acc[mi][i][0] = x0; acc[mi][i][1] = x1; acc[mi][i][2] = x2; acc[mi][i][3] = x3;
+            }
+            s += (x0 + x1) + (x2 + x3);
+            ss += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+        }
+    }
+    __syncthreads();                                                 // every wave's GEMM reads of the band are done
+#pragma unroll
+    for (int mi = 0; mi < MW; ++mi) {
+        const int ch0 = (m0 + mi) * 16 + 4 * kg;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[mi][i][e];
+            *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
+        }
+    }
+    __syncthreads();
+    constexpr int WBc = G::PWB - 2, C8 = COUT / 8;
+    bf16x8 *dst = reinterpret_cast<bf16x8 *>(zout + (size_t)band * R * WBc * COUT);
+    for (int q = threadIdx.x; q < R * WBc * C8; q += THREADS) {       // whole rows: consecutive threads, consecutive 16-B chunks
+        const int pb = q / C8, part = q - pb * C8, rr = pb / WBc, x = pb - rr * WBc;
+        dst[q] = *reinterpret_cast<const bf16x8 *>(tile + ((rr + 1) * G::PWB + x + 1) * CSF + part * 8);
+    }
+    __syncthreads();                                                 // the tile is rebuilt by the next band
+}
+
+__device__ __forceinline__ void band_stats(float s, float ss, float cnt, float *red, float &rstd, float &shift)
+{
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = s; red[WAVES + wave] = ss; }
+    __syncthreads();
+    float S = 0.0f, SS = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { S += red[w]; SS += red[WAVES + w]; }
+    __syncthreads();                                                 // red[] is reused by the next layer
+    const float mean = S / cnt;
+    const float var = fmaxf(SS / cnt - mean * mean, 0.0f);
+    rstd = 1.0f / sqrtf(var + LN_EPS);
+    shift = -mean * rstd;
+}
+
+template <int HB, int WB, int R, bool BITS>
+__global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_params prm, const void *__restrict__ obs_in, bf16 *__restrict__ feat,
+                                                                     bf16 *__restrict__ scratch, int N)
+{
+    using G = BandGeo<HB, WB, R>;
+    __shared__ __attribute__((aligned(16))) bf16 tile[G::NPOSB * CSF];
+    __shared__ float red[2 * WAVES];
+    __shared__ uint32_t obw[BITS ? G::OWB : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
+    bf16 *const zA = scratch + (size_t)blockIdx.x * 2 * G::P * 128, *const zB = zA + (size_t)G::P * 128;
+    for (int i = tid; i < G::NPOSB * CSF / 8; i += THREADS) {
+        bf16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
+        reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
+    }
+    __syncthreads();
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        int lane_i = lane;
+        asm volatile("" : "+v"(lane_i));
+        const float *planes = reinterpret_cast<const float *>(obs_in) + (size_t)n * 12 * G::P;
+        if (BITS) {
+            for (int w = tid; w < G::OWB; w += THREADS) obw[BITS ? w : 0] = reinterpret_cast<const uint32_t *>(obs_in)[(size_t)n * G::OWB + w];
+            __syncthreads();
+        }
+        float s, ss, rstd, shift;
+        // layer 1: 12 (-> 32) -> 32 channels
+        s = ss = 0.0f;
+#pragma unroll 1
+        for (int band = 0; band < G::NB; ++band) {
+            band_load_obs<G, R, BITS>(tile, obw, planes, band);
+            __syncthreads();
+            band_conv<G, R, 32, 32, 1, G::NT / 2, false>(prm.layer[0], tile, zA, band, lane_i, wave & 1, (wave >> 1) * (G::NT / 2), s, ss);
+        }
+        band_stats(s, ss, (float)(32 * G::P), red, rstd, shift);
+        // layer 2: 32 -> 64
+        s = ss = 0.0f;
+#pragma unroll 1
+        for (int band = 0; band < G::NB; ++band) {
+            band_load_norm<G, R, 32>(tile, zA, prm.layer[0].ln, rstd, shift, band);
+            __syncthreads();
+            band_conv<G, R, 32, 64, 1, G::NT, false>(prm.layer[1], tile, zB, band, lane_i, wave, 0, s, ss);
+        }
+        band_stats(s, ss, (float)(64 * G::P), red, rstd, shift);
+        // layer 3: 64 -> 128
+        s = ss = 0.0f;
+#pragma unroll 1
+        for (int band = 0; band < G::NB; ++band) {
+            band_load_norm<G, R, 64>(tile, zB, prm.layer[1].ln, rstd, shift, band);
+            __syncthreads();
+            band_conv<G, R, 64, 128, 2, G::NT, false>(prm.layer[2], tile, zA, band, lane_i, wave * 2, 0, s, ss);
+        }
+        band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
+        // layer 4: 128 -> 128, + residual
+        s = ss = 0.0f;
+#pragma unroll 1
+        for (int band = 0; band < G::NB; ++band) {
+            band_load_norm<G, R, 128>(tile, zA, prm.layer[2].ln, rstd, shift, band);
+            __syncthreads();
+            band_conv<G, R, 128, 128, 2, G::NT, true>(prm.layer[3], tile, zB, band, lane_i, wave * 2, 0, s, ss);
+        }
+        band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
+        // features: relu(LN4(z4)), channels-last [P][128]
+        {
+            constexpr int ITEMS = G::P * 16, CH = 4;
+            bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * G::P * 128);
+#pragma unroll 1
+            for (int q0 = tid; q0 < ITEMS; q0 += CH * THREADS) {
+                bf16x8 z[CH];
+                f16x8 l0[CH], l1[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int q = min(q0 + j * THREADS, ITEMS - 1);
+                    z[j] = reinterpret_cast<const bf16x8 *>(zB)[q];
+                    const _Float16 *lq = reinterpret_cast<const _Float16 *>(prm.layer[3].ln) + (size_t)q * 16;
+                    l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+                    l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+                }
+                POL_PIN();
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int q = q0 + j * THREADS;
+                    if (q < ITEMS) dst[q] = ln_relu8(z[j], l0[j], l1[j], rstd, shift);
+                }
+            }
+        }
+        __syncthreads();                                             // zB / obw are rewritten by the next sample
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // Backward of the trunk for the PPO update: per sample, layer 4 -> 1,
 //   dy  = da * [x^ w + b > 0]                       (ReLU mask recomputed from the saved x^)
 //   dx^ = dy * w
@@ -959,14 +1250,14 @@ __global__ __launch_bounds__(256) void k_pack_conv(const float *__restrict__ w, 
 }
 
 // pack_ln: LayerNorm([C,10,15]) weight / bias f32 -> fp16 [150][C/4][weight x4 | bias x4]
-__global__ __launch_bounds__(256) void k_pack_ln(const float *__restrict__ w, const float *__restrict__ b, int cout, _Float16 *__restrict__ out)
+__global__ __launch_bounds__(256) void k_pack_ln(const float *__restrict__ w, const float *__restrict__ b, int cout, int pixels, _Float16 *__restrict__ out)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;                        // one (pixel, channel)
-    if (e >= P * cout) return;
+    if (e >= pixels * cout) return;
     const int p = e / cout, c = e - p * cout;
     _Float16 *o = out + ((size_t)p * cout + (c & ~3)) * 2 + (c & 3);
-    o[0] = (_Float16)w[(size_t)c * P + p];
-    o[4] = (_Float16)b[(size_t)c * P + p];
+    o[0] = (_Float16)w[(size_t)c * pixels + p];
+    o[4] = (_Float16)b[(size_t)c * pixels + p];
 }
 
 // obs_to_x0: the observation as the weight-gradient kernel's layer-1 operand, bf16 channels-last [N][150][16] (12 planes + 4 zero channels),
@@ -1033,10 +1324,10 @@ extern "C" int inv_policy_pack_conv(const float *w, int32_t cout, int32_t cin, i
     return launch_status("inv_policy_pack_conv");
 }
 
-extern "C" int inv_policy_pack_ln(const float *weight, const float *bias, int32_t cout, void *out_f16, void *stream)
+extern "C" int inv_policy_pack_ln(const float *weight, const float *bias, int32_t cout, int32_t pixels, void *out_f16, void *stream)
 {
-    if (!weight || !bias || !out_f16 || cout < 4 || (cout & 3)) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_pack_ln: NULL tensor or cout not a multiple of 4");
-    hipLaunchKernelGGL(pol::k_pack_ln, dim3((pol::P * cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, bias, (int)cout,
+    if (!weight || !bias || !out_f16 || cout < 4 || (cout & 3) || pixels < 1) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_pack_ln: NULL tensor, cout not a multiple of 4 or pixels < 1");
+    hipLaunchKernelGGL(pol::k_pack_ln, dim3((pixels * cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight, bias, (int)cout, (int)pixels,
                        reinterpret_cast<_Float16 *>(out_f16));
     return launch_status("inv_policy_pack_ln");
 }
@@ -1073,6 +1364,31 @@ static int launch_trunk(const inv_policy_params *params, const void *obs, bool b
         hipLaunchKernelGGL((pol::k_policy_trunk<false, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
                            reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, none);
     return launch_status("inv_policy_trunk");
+}
+
+
+extern "C" int64_t inv_policy_trunk_banded_scratch_bytes(int32_t height, int32_t width)
+{
+    if (height != 32 || width != 32) return 0;
+    return (int64_t)2 * inv_cu_count() * 2 * (int64_t)height * width * 128 * 2;          // 2 workgroups per CU, two [P][128] bf16 buffers each
+}
+
+extern "C" int inv_policy_trunk_banded(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, int32_t height, int32_t width,
+                                       void *feat_bf16, void *scratch, int64_t scratch_bytes, int32_t N, void *stream)
+{
+    if (!params || !obs || !feat_bf16 || !scratch || N < 0 || !layers_ok(params))
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_banded: NULL params / obs / feat / scratch, a NULL layer tensor, or N < 0");
+    if (height != 32 || width != 32) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_trunk_banded: built for the 32 x 32 board (got %d x %d)", (int)width, (int)height);
+    if (scratch_bytes < inv_policy_trunk_banded_scratch_bytes(height, width)) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_banded: scratch too small");
+    if (N == 0) return INV_OK;
+    const int grid = trunk_grid(N);
+    if (obs_is_bits)
+        hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), reinterpret_cast<pol::bf16 *>(scratch), (int)N);
+    else
+        hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), reinterpret_cast<pol::bf16 *>(scratch), (int)N);
+    return launch_status("inv_policy_trunk_banded");
 }
 
 extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *obs, void *feat_bf16, int32_t N, void *stream)

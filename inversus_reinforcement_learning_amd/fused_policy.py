@@ -7,7 +7,8 @@ Weights are re-packed from the f32 `nn.Module` by `refresh()` -- call it after e
 you want the actor to see.  Inference only: the PPO update keeps using the autograd module.
 
 Numerics: bf16 operands with f32 accumulation, i.e. NOT bit-equal to the f32 module; logits agree to
-~1e-2 (tests/test_gpu_policy.py).  Only the 12 x 10 x 15 observation of the reference is supported.
+~1e-2 (tests/test_gpu_policy.py).  Boards: the reference's 15 x 10 (activations resident in LDS) and the 32 x 32 stress board
+of BASELINE config C5 (inference only: the "banded" kernel streams the layers' pre-norm outputs through a scratch buffer).
 """
 import ctypes as C
 
@@ -44,12 +45,13 @@ def pack_conv(w, cin_pad, transposed=False):
 
 
 def pack_ln(weight, bias, cout):
-    """LayerNorm([C,10,15]) affine -> fp16 [150][C/4][weight x4 | bias x4] as one kernel (inv_policy_pack_ln)."""
+    """LayerNorm([C,H,W]) affine -> fp16 [H*W][C/4][weight x4 | bias x4] as one kernel (inv_policy_pack_ln)."""
     lib = L.load()
     w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-    out = torch.empty((150, cout // 4, 8), dtype=torch.float16, device=w.device)
+    pixels = w.numel() // int(cout)
+    out = torch.empty((pixels, cout // 4, 8), dtype=torch.float16, device=w.device)
     with torch.cuda.device(w.device):
-        rc = lib.inv_policy_pack_ln(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), int(cout), C.c_void_p(out.data_ptr()),
+        rc = lib.inv_policy_pack_ln(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), int(cout), pixels, C.c_void_p(out.data_ptr()),
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
     L.raise_for(rc, lib)
     return out
@@ -76,8 +78,21 @@ class FusedPolicy:
         dev = p.conv1.weight.device
         if dev.type != "cuda":
             raise RuntimeError("FusedPolicy needs the policy on the GPU")
-        if tuple(p.norm1.normalized_shape) != (32, 10, 15) or p.conv1.in_channels != 12:
-            raise ValueError("the fused trunk supports the reference's 12 x 10 x 15 observation only")
+        shape = tuple(p.norm1.normalized_shape)
+        if shape not in ((32, 10, 15), (32, 32, 32)) or p.conv1.in_channels != 12:
+            raise ValueError("the fused trunk supports 12-channel observations of the 15 x 10 and 32 x 32 boards only")
+        self.H, self.W = shape[1], shape[2]
+        self.P = self.H * self.W
+        self.OW = (12 * self.P + 31) // 32
+        self.banded = (self.H, self.W) != (10, 15)
+        if self.banded and self.train_numerics:
+            raise ValueError("the fused update (and its rollout numerics) exists for the 15 x 10 board only")
+        if self.banded:
+            nbytes = int(self.lib.inv_policy_trunk_banded_scratch_bytes(self.H, self.W))
+            if nbytes <= 0:
+                raise ValueError(f"no fused trunk for a {self.W} x {self.H} board")
+            if getattr(self, "_scratch", None) is None or self._scratch.numel() < nbytes:
+                self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._keep = []
         params = L.InvPolicyParams()
         for i, (conv, norm) in enumerate(((p.conv1, p.norm1), (p.conv2, p.norm2), (p.conv3, p.norm3), (p.conv4, p.norm4))):
@@ -94,26 +109,34 @@ class FusedPolicy:
         firsts = [p.fc_actor[0]] if self.actor_only else [p.fc_actor[0], p.fc_critic[0]]
         w1 = torch.cat([m.weight for m in firsts]).detach().float()                         # [512 (256: actor only), 19204]
         hid = w1.shape[0]
-        self.w1_feat = w1[:, :19200].reshape(hid, 128, 150).permute(0, 2, 1).reshape(hid, 19200).contiguous().to(torch.bfloat16)
-        self.w1_extra = w1[:, 19200:].contiguous()
+        nf = 128 * self.P
+        self.w1_feat = w1[:, :nf].reshape(hid, 128, self.P).permute(0, 2, 1).reshape(hid, nf).contiguous().to(torch.bfloat16)
+        self.w1_extra = w1[:, nf:].contiguous()
         self.b1 = torch.cat([m.bias for m in firsts]).detach().float()
         self.hidden = p.fc_actor[0].out_features
 
     @torch.no_grad()
     def features(self, grid):
-        """Trunk only: bf16 [B, 19200] in channels-last order.  `grid`: f32 planes [B,12,10,15] or the packed
-        observations [B, 57] int32 that the env writes under INV_STEP_OBS_BITS (32x fewer bytes to read)."""
-        if grid.dtype == torch.int32:
-            if grid.dim() != 2 or grid.shape[1] != 57:
-                raise ValueError(f"packed observations must be [B, 57] int32, got {tuple(grid.shape)}")
+        """Trunk only: bf16 [B, H*W*128] in channels-last order.  `grid`: f32 planes [B,12,H,W] or the packed
+        observations [B, ceil(12*H*W/32)] int32 that the env writes under INV_STEP_OBS_BITS (32x fewer bytes to read)."""
+        bits = grid.dtype == torch.int32
+        if bits:
+            if grid.dim() != 2 or grid.shape[1] != self.OW:
+                raise ValueError(f"packed observations must be [B, {self.OW}] int32, got {tuple(grid.shape)}")
             grid, fn = grid.contiguous(), self.lib.inv_policy_trunk_bits
         else:
+            if tuple(grid.shape[1:]) != (12, self.H, self.W):
+                raise ValueError(f"observations must be [B, 12, {self.H}, {self.W}], got {tuple(grid.shape)}")
             grid, fn = grid.contiguous().float(), self.lib.inv_policy_trunk
-        feat = torch.empty((grid.shape[0], 19200), dtype=torch.bfloat16, device=grid.device)
+        feat = torch.empty((grid.shape[0], 128 * self.P), dtype=torch.bfloat16, device=grid.device)
         with torch.cuda.device(grid.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if self.train_numerics:
-                rc = self.lib.inv_policy_trunk_train_fwd(C.byref(self.params), C.c_void_p(grid.data_ptr()), int(grid.dtype == torch.int32),
+            if self.banded:
+                rc = self.lib.inv_policy_trunk_banded(C.byref(self.params), C.c_void_p(grid.data_ptr()), int(bits), self.H, self.W,
+                                                      C.c_void_p(feat.data_ptr()), C.c_void_p(self._scratch.data_ptr()), self._scratch.numel(),
+                                                      grid.shape[0], st)
+            elif self.train_numerics:
+                rc = self.lib.inv_policy_trunk_train_fwd(C.byref(self.params), C.c_void_p(grid.data_ptr()), int(bits),
                                                          C.c_void_p(feat.data_ptr()), None, grid.shape[0], st)
             else:
                 rc = fn(C.byref(self.params), C.c_void_p(grid.data_ptr()), C.c_void_p(feat.data_ptr()), grid.shape[0], st)

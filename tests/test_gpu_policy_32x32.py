@@ -1,0 +1,90 @@
+"""The banded fused trunk (csrc/inv_policy.hip: k_policy_trunk_banded) on the 32 x 32 board of BASELINE config C5 against the
+f32 module (inversus_rl/policies.py:91-99 with LayerNorm([C,32,32])).  bf16 operands / f32 accumulation, z rounded to bf16
+before its LayerNorm: features within 0.15 abs (131 072 features per sample: the maximum is a tail statistic; measured 0.09) / 0.01 mean-abs of the f32 module's (15 x 10 kernel: 0.06 / 0.008), logits and
+values within 0.05.  Packed and f32 observations give bit-equal features."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_policy(torch, seed=0):
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    torch.manual_seed(seed)
+    pol = InversusCNNPolicy(12, 32, 32, 4).cuda().eval()
+    with torch.no_grad():                                    # non-trivial LayerNorm affine parameters
+        for nm in (pol.norm1, pol.norm2, pol.norm3, pol.norm4):
+            nm.weight.add_(0.3 * torch.randn_like(nm.weight))
+            nm.bias.add_(0.3 * torch.randn_like(nm.bias))
+    return pol
+
+
+def env_observations(torch, n, steps=12):
+    """Real observations of the 32 x 32 env after some play (planes and the packed form of the same states)."""
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    b = DeviceEnvBatch(n, 32, 32, opponent="dummy", difficulty="hard", opp_seed=3)
+    b.seed(np.arange(n, dtype=np.int64)); b.reset()
+    for t in range(steps):
+        b.step(b.uniform_actions(9, t), None, auto_reset=True, obs=False)
+    planes, extra = b.render(0)
+    bits, _ = b.render(0, bits=True)
+    return planes, bits, extra
+
+
+@pytest.mark.parametrize("n", [1, 37, 600])
+def test_banded_trunk_matches_the_f32_module(n):
+    import torch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    pol = make_policy(torch)
+    fused = FusedPolicy(pol)
+    assert fused.banded and fused.P == 1024 and fused.OW == 384
+    planes, bits, extra = env_observations(torch, n)
+    feat = fused.features(planes).float()
+    with torch.no_grad():
+        want = pol.trunk(planes).reshape(n, 128, 1024).permute(0, 2, 1).reshape(n, 128 * 1024)
+    err = (feat - want).abs()
+    print("features: max", float(err.max()), "mean", float(err.mean()), "absmax of the reference", float(want.abs().max()))
+    assert float(err.max()) < 0.15 and float(err.mean()) < 0.01
+    assert torch.equal(fused.features(bits), fused.features(planes))          # the packed observation is the same input
+    logits, value = fused(bits, extra)
+    with torch.no_grad():
+        lw, vw = pol(planes, extra)
+    assert float((logits - lw).abs().max()) < 0.05 and float((value - vw).abs().max()) < 0.05
+
+
+def test_banded_trunk_rejects_other_boards_and_the_fused_update():
+    import torch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    with pytest.raises(ValueError):
+        FusedPolicy(InversusCNNPolicy(12, 16, 16, 4).cuda())
+    with pytest.raises(ValueError):
+        FusedPolicy(InversusCNNPolicy(12, 32, 32, 4).cuda(), train_numerics=True)
+    fused = FusedPolicy(make_policy(torch))
+    with pytest.raises(ValueError):
+        fused.features(torch.zeros(4, 12, 10, 15, device="cuda"))
+    with pytest.raises(ValueError):
+        fused.features(torch.zeros(4, 57, dtype=torch.int32, device="cuda"))
+
+
+def test_selfplay_collector_on_32x32_with_fused_actors():
+    """C5 with the policy in the loop: packed observations of the 32 x 32 env into the banded trunk, both actors fused."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    n = 256
+    b = DeviceEnvBatch(n, 32, 32, opponent="selfplay")
+    b.seed(np.arange(n, dtype=np.int64)); b.reset()
+    torch.manual_seed(0)
+    agent = PPOAgent(InversusCNNPolicy(12, 32, 32, 4), fused_act=True)
+    opp = FusedPolicy(InversusCNNPolicy(12, 32, 32, 4).cuda().eval(), actor_only=True)
+    col = RolloutCollector(b, agent, opp)
+    assert col.packed
+    col.collect(6)
+    assert all(g.dtype == torch.int32 and tuple(g.shape) == (n, 384) for g in agent.obs_grid_buffer)
+    lp = torch.stack(agent.log_prob_buffer)
+    assert torch.isfinite(lp).all() and float(lp.mean()) < -2.0                  # near-uniform random-init policy: log(1/13) = -2.56
+    b.check()
