@@ -269,6 +269,28 @@ def side_measurements(torch, np, n):
         return res
     guard("policy in the loop (selfplay, fused bf16 trunk, 2 forwards/step)", policy_cfg)
 
+    def policy32_cfg():
+        """BASELINE config C5 with the policy in the loop: the banded fused trunk on the 32 x 32 board and a self-play collector."""
+        from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+        from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+        from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+        from inversus_reinforcement_learning_amd.training import RolloutCollector
+        torch.manual_seed(0)
+        b = DeviceEnvBatch(n, 32, 32, K, opponent="selfplay")
+        b.seed(np.arange(n, dtype=np.int64)); b.reset()
+        pol = InversusCNNPolicy(12, 32, 32, 4).cuda().eval()
+        agent = PPOAgent(pol, fused_act=True)
+        bits, _ = b.render(0, bits=True)
+        ms = timed(lambda: agent.fused.features(bits), 3, warm=1) / 1e3
+        col = RolloutCollector(b, agent, FusedPolicy(InversusCNNPolicy(12, 32, 32, 4).cuda().eval(), actor_only=True))
+        col.collect(3); agent.reset_buffers(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); col.collect(3); torch.cuda.synchronize()
+        rate = round(3 * n / (time.perf_counter() - t0))
+        agent.reset_buffers()
+        return {"banded_fused_trunk_ms": round(ms, 2), "TFLOPs": round(497.7e6 * n / (ms * 1e-3) / 1e12, 1),
+                "selfplay_collector_env_steps_per_s": rate}
+    guard("C5 with the policy: 32x32 banded fused trunk + self-play collector (packed obs, 2 forwards/step)", policy32_cfg)
+
     def update_cfg():
         """PPO update over a packed self-play rollout, trunk forward/backward in the fused kernels (fused_update=True)."""
         from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy

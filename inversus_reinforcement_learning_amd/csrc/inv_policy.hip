@@ -524,8 +524,12 @@ __device__ __forceinline__ bf16x8 ln_relu8(const bf16x8 z, const f16x8 l0, const
 template <class G, int R, int CPREV>
 __device__ __forceinline__ void band_load_norm(bf16 *tile, const bf16 *__restrict__ zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band)
 {
-    constexpr int C8 = CPREV / 8, ITEMS = G::TR * G::PWB * C8, NIT = (ITEMS + THREADS - 1) / THREADS, CH = 4;
-    const int tid = threadIdx.x;
+    constexpr int C8 = CPREV / 8, ITEMS = G::TR * G::PWB * C8, NIT = (ITEMS + THREADS - 1) / THREADS, CH = NIT < 7 ? NIT : 7;
+    // The item coordinates depend on the thread id only: hipcc hoists them out of the band loop and keeps ~4 registers per
+    // item live across the GEMM, which then spills its weight pointers (scratch_load + s_waitcnt vmcnt(0) in every k-step).
+    // Laundering the id makes them cheap per-band recomputations.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
 #pragma unroll 1
     for (int k0 = 0; k0 < NIT; k0 += CH) {
         bf16x8 z[CH];
@@ -565,7 +569,9 @@ template <class G, int R, bool BITS>
 __device__ __forceinline__ void band_load_obs(bf16 *tile, const uint32_t *obw, const float *__restrict__ planes, int band)
 {
     constexpr int WBc = G::PWB - 2, HBc = G::P / WBc;
-    for (int z = threadIdx.x; z < G::TR * G::PWB * 8; z += THREADS) {       // one 8-byte quad (4 channels) per item
+    int tid0 = threadIdx.x;
+    asm volatile("" : "+v"(tid0));
+    for (int z = tid0; z < G::TR * G::PWB * 8; z += THREADS) {              // one 8-byte quad (4 channels) per item
         const int pos = z >> 3, part = z & 7, tr = pos / G::PWB, tc = pos - tr * G::PWB;
         const int y = band * R + tr - 1, x = tc - 1;
         uint32_t lo = 0u, hi = 0u;
@@ -592,6 +598,7 @@ template <class G, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL>
 __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile, bf16 *__restrict__ zout, int band, int lane, int m0, int n0, float &s, float &ss)
 {
     constexpr int KPT = CIN / 32, KS = 9 * KPT;
+    asm volatile("" : "+v"(lane));
     const int c16 = lane & 15, kg = lane >> 4;
     int base[NW], tap0[NW];
 #pragma unroll
@@ -664,7 +671,9 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
     __syncthreads();
     constexpr int WBc = G::PWB - 2, C8 = COUT / 8;
     bf16x8 *dst = reinterpret_cast<bf16x8 *>(zout + (size_t)band * R * WBc * COUT);
-    for (int q = threadIdx.x; q < R * WBc * C8; q += THREADS) {       // whole rows: consecutive threads, consecutive 16-B chunks
+    int tid1 = threadIdx.x;
+    asm volatile("" : "+v"(tid1));
+    for (int q = tid1; q < R * WBc * C8; q += THREADS) {             // whole rows: consecutive threads, consecutive 16-B chunks
         const int pb = q / C8, part = q - pb * C8, rr = pb / WBc, x = pb - rr * WBc;
         dst[q] = *reinterpret_cast<const bf16x8 *>(tile + ((rr + 1) * G::PWB + x + 1) * CSF + part * 8);
     }
