@@ -236,7 +236,8 @@ typedef struct { void *xhat[4]; void *act[3]; float *rstd; } inv_policy_saved;
 typedef struct { const void *wt[3]; const void *ln[4]; } inv_policy_bwd_params;
 typedef struct { void *dy[4]; void *dz[4]; } inv_policy_grads;
 /* saved == NULL: the same numerics (x^ rounded to bf16 before the affine) with nothing stored -- the rollout forward to use
- * when inv_policy_trunk_bwd-based updates follow, so that the update's first forward reproduces the rollout's features. */
+ * when inv_policy_trunk_bwd-based updates follow, so that the update's first forward reproduces the rollout's features
+ * BIT FOR BIT (tests/test_gpu_fused_train.py); it runs the inference kernel's epilogue, at the inference kernel's speed. */
 int  inv_policy_trunk_train_fwd(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, void *feat_bf16,
                                 const inv_policy_saved *saved, int32_t N, void *stream);
 int  inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const inv_policy_saved *saved, const void *dfeat_bf16,

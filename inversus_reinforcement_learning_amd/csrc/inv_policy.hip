@@ -134,10 +134,15 @@ __device__ __forceinline__ float wave_sum(float x)
 // x^ = (z - mean) * rstd and the activation, both bf16 channels-last [150][COUT] of this sample, and rstd.
 struct LayerSave { bf16 *xhat; bf16 *act; float *rstd; };
 
-template <int CIN, int COUT, int MW, int NW, bool RAGGED, bool RESIDUAL, bool SAVE = false>
+template <int CIN, int COUT, int MW, int NW, bool RAGGED, bool RESIDUAL, bool SAVE = false, bool TN = false>
 __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *tile, float *red, int lane, int m0, int n0, int ncount,
                                              unsigned long long &stamp_prev, int layer, const LayerSave sv = LayerSave{ nullptr, nullptr, nullptr })
 {
+    // Every fused multiply-add below is written as fmaf: with contraction left to the backend the SAVE and inference
+    // instantiations fused the sum of squares differently (v_mul + v_fmac vs v_pk_mul + v_add), rstd differed in the last
+    // bit for some samples and ~4e-7 of the features by one bf16 ulp -- the training forward and the rollout forward with
+    // its numerics (TN) must agree bit for bit.
+#pragma clang fp contract(off)
     constexpr int KPT = CIN / 32, KS = 9 * KPT;
     const int c16 = lane & 15, kg = lane >> 4;
 
@@ -242,7 +247,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             // only the wave's LAST tile can hold columns past pixel 149 (150 = 9 x 16 + 6): every other tile is summed
             // unconditionally and the last one through a 0 / 1 factor -- no exec-mask branch per tile (the per-tile `if`
             // compiled to 20 s_and_saveexec / s_cbranch pairs with out-of-line bodies per layer and wave)
-            const float t1 = (x0 + x1) + (x2 + x3), t2 = (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+            const float t1 = (x0 + x1) + (x2 + x3), t2 = fmaf(x0, x0, x1 * x1) + fmaf(x2, x2, x3 * x3);
             if (i + 1 < NW) { s += t1; ss += t2; }
             else { s = fmaf(vlast, t1, s); ss = fmaf(vlast, t2, ss); }
         }
@@ -260,7 +265,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) { S += red[w]; SS += red[WAVES + w]; }
     const float mean = S / cnt;
-    const float var = fmaxf(SS / cnt - mean * mean, 0.0f);
+    const float var = fmaxf(fmaf(-mean, mean, SS / cnt), 0.0f);
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
     const float shift = -mean * rstd;
     if (SAVE && sv.rstd && threadIdx.x == 0) *sv.rstd = rstd;
@@ -311,10 +316,14 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
                 if (POL_ROWTILES ? vcol : (i + 1 < NW || pix[i] < P)) {
                     bf16x4 o;
                     const f16x8 q = ln[mi][i];
-                    o[0] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][0], rstd, shift), (float)q[0], (float)q[4]), 0.0f);
-                    o[1] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][1], rstd, shift), (float)q[1], (float)q[5]), 0.0f);
-                    o[2] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][2], rstd, shift), (float)q[2], (float)q[6]), 0.0f);
-                    o[3] = (bf16)fmaxf(fmaf(fmaf(acc[mi][i][3], rstd, shift), (float)q[3], (float)q[7]), 0.0f);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float xh = fmaf(acc[mi][i][e], rstd, shift);
+                        // TN (train numerics): x^ rounded to bf16 before the affine, the same operations on the same operands as the
+                        // training forward's row pass (SAVE) -- bit-identical features without its extra barrier and row pass
+                        if (TN) xh = (float)(bf16)xh;
+                        o[e] = (bf16)fmaxf(fmaf(xh, (float)q[e], (float)q[4 + e]), 0.0f);
+                    }
                     // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
                     // above, and the residual read of this lane's own elements precedes this write
                     *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
@@ -358,7 +367,7 @@ __device__ __forceinline__ void stagger_second_workgroup(int tid, float *red)
 
 // BITS: the observation arrives as the packed bitstring inv_step writes under INV_STEP_OBS_BITS (57 words per sample).
 // SAVE: training forward -- every layer also stores x^, its activation and rstd for k_policy_trunk_bwd.
-template <bool BITS, bool SAVE>
+template <bool BITS, bool SAVE, bool TN = false>
 __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params prm, const void *__restrict__ obs_in,
                                                           bf16 *__restrict__ feat, int N, inv_policy_saved sv)
 {
@@ -446,34 +455,33 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
         // waves), which also leaves the register allocator enough room to keep the epilogue out of scratch.
         if (SAVE) {
             const size_t sn = (size_t)n * P;
-            const bool keep = sv.rstd != nullptr;       // saved == NULL: the training NUMERICS (x^ rounded to bf16) without the stores
-            bf16 *const xh0 = keep ? reinterpret_cast<bf16 *>(sv.xhat[0]) + sn * 32 : nullptr, *const xh1 = keep ? reinterpret_cast<bf16 *>(sv.xhat[1]) + sn * 64 : nullptr;
-            bf16 *const xh2 = keep ? reinterpret_cast<bf16 *>(sv.xhat[2]) + sn * 128 : nullptr, *const xh3 = keep ? reinterpret_cast<bf16 *>(sv.xhat[3]) + sn * 128 : nullptr;
-            bf16 *const ac0 = keep ? reinterpret_cast<bf16 *>(sv.act[0]) + sn * 32 : nullptr, *const ac1 = keep ? reinterpret_cast<bf16 *>(sv.act[1]) + sn * 64 : nullptr;
-            bf16 *const ac2 = keep ? reinterpret_cast<bf16 *>(sv.act[2]) + sn * 128 : nullptr;
-            float *const rs = keep ? sv.rstd + (size_t)n * 4 : nullptr;
+            bf16 *const xh0 = reinterpret_cast<bf16 *>(sv.xhat[0]) + sn * 32, *const xh1 = reinterpret_cast<bf16 *>(sv.xhat[1]) + sn * 64;
+            bf16 *const xh2 = reinterpret_cast<bf16 *>(sv.xhat[2]) + sn * 128, *const xh3 = reinterpret_cast<bf16 *>(sv.xhat[3]) + sn * 128;
+            bf16 *const ac0 = reinterpret_cast<bf16 *>(sv.act[0]) + sn * 32, *const ac1 = reinterpret_cast<bf16 *>(sv.act[1]) + sn * 64;
+            bf16 *const ac2 = reinterpret_cast<bf16 *>(sv.act[2]) + sn * 128;
+            float *const rs = sv.rstd + (size_t)n * 4;
             conv_ln_relu<32, 32, 1, 5, false, false, true>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0, LayerSave{ xh0, ac0, rs });
-            conv_ln_relu<32, 64, 1, 10, false, false, true>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1, LayerSave{ xh1, ac1, keep ? rs + 1 : nullptr });
+            conv_ln_relu<32, 64, 1, 10, false, false, true>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1, LayerSave{ xh1, ac1, rs + 1 });
 #if POL_ROWTILES
-            conv_ln_relu<64, 128, 2, 10, false, false, true>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2, LayerSave{ xh2, ac2, keep ? rs + 2 : nullptr });
-            conv_ln_relu<128, 128, 2, 10, false, true, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3, LayerSave{ xh3, nullptr, keep ? rs + 3 : nullptr });
+            conv_ln_relu<64, 128, 2, 10, false, false, true>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2, LayerSave{ xh2, ac2, rs + 2 });
+            conv_ln_relu<128, 128, 2, 10, false, true, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3, LayerSave{ xh3, nullptr, rs + 3 });
 #else
-            conv_ln_relu<64, 128, 4, 5, false, false, true>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2, LayerSave{ xh2, ac2, keep ? rs + 2 : nullptr });
-            conv_ln_relu<128, 128, 4, 5, false, true, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3, LayerSave{ xh3, nullptr, keep ? rs + 3 : nullptr });
+            conv_ln_relu<64, 128, 4, 5, false, false, true>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2, LayerSave{ xh2, ac2, rs + 2 });
+            conv_ln_relu<128, 128, 4, 5, false, true, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3, LayerSave{ xh3, nullptr, rs + 3 });
 #endif
         } else {
-        conv_ln_relu<32, 32, 1, 5, false, false>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
+        conv_ln_relu<32, 32, 1, 5, false, false, false, TN>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
 #ifdef POL_CONV2_2x5
-        conv_ln_relu<32, 64, 2, 5, false, false>(prm.layer[1], tile, red, lane_i, (wave & 1) * 2, (wave >> 1) * 5, 5, stamp_prev, 1);
+        conv_ln_relu<32, 64, 2, 5, false, false, false, TN>(prm.layer[1], tile, red, lane_i, (wave & 1) * 2, (wave >> 1) * 5, 5, stamp_prev, 1);
 #else
-        conv_ln_relu<32, 64, 1, 10, false, false>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
+        conv_ln_relu<32, 64, 1, 10, false, false, false, TN>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
 #endif
 #if POL_ROWTILES
-        conv_ln_relu<64, 128, 2, 10, false, false>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2);
-        conv_ln_relu<128, 128, 2, 10, false, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3);
+        conv_ln_relu<64, 128, 2, 10, false, false, false, TN>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2);
+        conv_ln_relu<128, 128, 2, 10, false, true, false, TN>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3);
 #else
-        conv_ln_relu<64, 128, 4, 5, false, false>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2);
-        conv_ln_relu<128, 128, 4, 5, false, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3);
+        conv_ln_relu<64, 128, 4, 5, false, false, false, TN>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2);
+        conv_ln_relu<128, 128, 4, 5, false, true, false, TN>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3);
 #endif
         }
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
@@ -1426,8 +1434,19 @@ extern "C" int inv_policy_trunk_train_fwd(const inv_policy_params *params, const
     if (N == 0) return INV_OK;
     const int grid = trunk_grid(N);
     inv_policy_saved sv;
-    memset(&sv, 0, sizeof sv);                       // saved == NULL: same numerics, nothing stored (rollouts that a fused update follows)
-    if (saved) sv = *saved;
+    memset(&sv, 0, sizeof sv);
+    if (!saved) {
+        // saved == NULL (rollouts that a fused update follows): the inference kernel with the training forward's numerics -- the same
+        // features bit for bit, without the training epilogue's extra barrier and row pass
+        if (obs_is_bits)
+            hipLaunchKernelGGL((pol::k_policy_trunk<true, false, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                               reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, sv);
+        else
+            hipLaunchKernelGGL((pol::k_policy_trunk<false, false, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                               reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, sv);
+        return launch_status("inv_policy_trunk_train_fwd");
+    }
+    sv = *saved;
     if (obs_is_bits)
         hipLaunchKernelGGL((pol::k_policy_trunk<true, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
                            reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, sv);

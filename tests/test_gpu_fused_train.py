@@ -57,6 +57,26 @@ def test_training_forward_matches_inference_trunk_and_saves_consistent_tensors(n
     with torch.no_grad():
         lm, vm = pol(gf, x)
     assert (lt - lm).abs().max() < 0.05 and (vt - vm).abs().max() < 0.05
+    # saved == NULL (the learner's rollout forward): the inference epilogue with the training forward's numerics, bit for bit
+    fr = FusedPolicy(pol, train_numerics=True)
+    with torch.no_grad():
+        assert torch.equal(fr.features(gf), f_train) and torch.equal(fr.features(gb), f_train)
+
+
+def test_rollout_forward_with_train_numerics_is_bitwise_the_training_forward():
+    """inv_policy_trunk_train_fwd(saved = NULL) is another instantiation of the kernel (inference epilogue + x^ rounded to bf16).
+    Both must fuse their multiply-adds the same way: with contraction left to the compiler the LayerNorm statistics differed in
+    the last bit and ~4e-7 of the features by one bf16 ulp (seen at n = 4096, not at n = 3)."""
+    import torch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.fused_train import FusedTrainPolicy
+    n = 4096
+    pol = _policy(3)
+    gf, gb, _ = _obs(n, seed=7)
+    ft, fr = FusedTrainPolicy(pol), FusedPolicy(pol, train_numerics=True)
+    with torch.no_grad():
+        want = ft.features(gb)
+        assert torch.equal(fr.features(gb), want) and torch.equal(fr.features(gf), want) and torch.equal(ft.features(gf), want)
 
 
 @pytest.mark.parametrize("n,packed", [(64, False), (333, True), (1300, True)])     # 1300 > 512 resident blocks: persistent loops
