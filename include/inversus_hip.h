@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define INV_ABI_VERSION 3
+#define INV_ABI_VERSION 4
 
 typedef enum {
     INV_OK = 0,
@@ -264,6 +264,48 @@ int  inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, float *p
 int  inv_policy_pack_conv(const float *w, int32_t cout, int32_t cin, int32_t cin_pad, int32_t transposed, void *out_bf16, void *stream);
 int  inv_policy_pack_ln(const float *weight, const float *bias, int32_t cout, int32_t pixels, void *out_f16, void *stream);
 int  inv_policy_obs_to_x0(const void *obs, int32_t obs_is_bits, void *x0_bf16, int32_t N, void *stream);
+
+/* ---- the policy heads after their first Linear ------------------------------------------
+ * Reference: inversus_rl/policies.py:60-75 (fc_actor, fc_critic = Linear(19204, 256) ReLU Linear(256, 128) ReLU Linear(128, 13 | 1))
+ * and :102-106.  The first Linear's big product  pre = features @ W1[:, :128 P]^T  (bf16 [B][256 nheads], columns 0..255 actor,
+ * 256..511 critic) is the caller's GEMM; these entry points are everything after it, forward and backward, one kernel each:
+ *     h = relu(pre + extra W1[:, 128 P:]^T + b1)      a2 = relu(W2 h + b2)      logits | value = W3 a2 + b3
+ * h and a2 are rounded to bf16, W2 / W3 are bf16 MFMA operands, accumulation / biases / the extra columns are f32.
+ * Packed operands (inv_heads_pack): MFMA A fragments of a [rows x cols] matrix padded to [mpad x kpad] (multiples of 16 / 32),
+ *     out[(mt * (kpad / 32) + ks) * 64 + lane][e] = M[mt * 16 + (lane & 15)][ks * 32 + (lane >> 4) * 8 + e]     (bf16, zero padding)
+ *   w2[h]  = W2 of head h            [128 x 256]          w2t[h] = its transpose [256 x 128]              (h = 0 actor, 1 critic)
+ *   w3[h]  = W3 of head h padded to  [16 x 128]           w3t[h] = its transpose [128 x 32]  (13 | 1 columns used)
+ *   we f32 [256 nheads][4] = W1[:, 128 P:],  b1 f32 [256 nheads],  b2[h] f32 [128],  b3[h] f32 [13 | 1].
+ * w2t / w3t are only read by inv_heads_bwd. */
+#define INV_HEADS_HID 256
+#define INV_HEADS_MID 128
+#define INV_HEADS_ACTIONS 13
+#define INV_HEADS_PACK_MAX 8
+typedef struct {
+    const void *w2[2], *w2t[2], *w3[2], *w3t[2];
+    const float *we, *b1, *b2[2], *b3[2];
+} inv_heads_params;
+/* one matrix to pack: out = fragments of M [rows x cols], M[r][k] = transposed ? src[k * ld + r] : src[r * ld + k] (src f32) */
+typedef struct { const float *src; void *dst; int32_t rows, cols, ld, transposed, mpad, kpad; } inv_heads_pack_item;
+typedef struct { inv_heads_pack_item item[INV_HEADS_PACK_MAX]; } inv_heads_pack_list;
+int  inv_heads_pack(const inv_heads_pack_list *list, int32_t count, void *stream);                  /* one launch for `count` matrices */
+/* First Linear, `rows` output rows: w f32 [rows][128 P + 4] (feature index c * P + p, nn.Flatten's order) -> wf bf16 [rows][128 P]
+ * in the trunk kernels' channels-last order p * 128 + c, and we f32 [rows][4]; and the gradient's way back (dwf bf16, dwe f32 ->
+ * grad_w f32 [rows][128 P + 4], overwritten). */
+int  inv_heads_pack_fc1(const float *w, int32_t rows, int32_t pixels, void *wf_bf16, float *we, void *stream);
+int  inv_heads_unpack_fc1_grad(const void *dwf_bf16, const float *dwe, int32_t rows, int32_t pixels, float *grad_w, void *stream);
+/* Forward.  nheads = 2: actor and critic (pre [B][512]); nheads = 1: actor only (pre [B][256], value may be NULL) -- the frozen
+ * self-play opponent.  logits f32 [B][13], value f32 [B].  h_save bf16 [B][256 nheads] and a2_save bf16 [B][128 nheads]: both or
+ * neither; what inv_heads_bwd needs.  The result for a sample does not depend on B or on its position in the batch. */
+int  inv_heads_fwd(const inv_heads_params *params, const void *pre_bf16, const float *extra, float *logits, float *value,
+                   void *h_save, void *a2_save, int32_t nheads, int32_t B, void *stream);
+/* Backward (both heads).  In: dlogits f32 [B][13], dvalue f32 [B], the saved h / a2, extra f32 [B][4].  Out: dpre bf16 [B][512]
+ * (= d loss / d pre, the operand of the first Linear's two backward GEMMs), da2 bf16 [B][256] (with h: the operands of
+ * dW2[h] = da2[:, 128 h:128 h + 128]^T h[:, 256 h:256 h + 256]), and ADDED into the f32 buffers of `grads` (zero them first):
+ * db1 [512], dwe [512][4], db2[h] [128], dw3[h] [13 | 1][128], db3[h] [13 | 1]. */
+typedef struct { float *db1, *dwe, *db2[2], *dw3[2], *db3[2]; } inv_heads_grads;
+int  inv_heads_bwd(const inv_heads_params *params, const float *dlogits, const float *dvalue, const void *h, const void *a2,
+                   const float *extra, void *dpre_bf16, void *da2_bf16, const inv_heads_grads *grads, int32_t B, void *stream);
 
 /* ---- the scalar tail of the PPO update ------------------------------------------------------
  * inv_ppo_loss: forward AND backward of the reference's minibatch loss (inversus_rl/ppo_agent.py:211-224)

@@ -61,6 +61,27 @@ class InvPolicyGrads(C.Structure):
     _fields_ = [("dy", C.c_void_p * 4), ("dz", C.c_void_p * 4)]
 
 
+class InvHeadsParams(C.Structure):
+    _fields_ = [("w2", C.c_void_p * 2), ("w2t", C.c_void_p * 2), ("w3", C.c_void_p * 2), ("w3t", C.c_void_p * 2),
+                ("we", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p * 2), ("b3", C.c_void_p * 2)]
+
+
+class InvHeadsPackItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("ld", C.c_int32),
+                ("transposed", C.c_int32), ("mpad", C.c_int32), ("kpad", C.c_int32)]
+
+
+INV_HEADS_PACK_MAX = 8
+
+
+class InvHeadsPackList(C.Structure):
+    _fields_ = [("item", InvHeadsPackItem * INV_HEADS_PACK_MAX)]
+
+
+class InvHeadsGrads(C.Structure):
+    _fields_ = [("db1", C.c_void_p), ("dwe", C.c_void_p), ("db2", C.c_void_p * 2), ("dw3", C.c_void_p * 2), ("db3", C.c_void_p * 2)]
+
+
 _V = C.c_void_p
 SIGNATURES = {
     "inv_last_error": (C.c_char_p, []),
@@ -97,6 +118,11 @@ SIGNATURES = {
     "inv_policy_trunk_banded_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "inv_policy_trunk_banded": (C.c_int, [P(InvPolicyParams), _V, C.c_int32, C.c_int32, C.c_int32, _V, _V, C.c_int64, C.c_int32, _V]),
     "inv_policy_obs_to_x0": (C.c_int, [_V, C.c_int32, _V, C.c_int32, _V]),
+    "inv_heads_pack": (C.c_int, [P(InvHeadsPackList), C.c_int32, _V]),
+    "inv_heads_pack_fc1": (C.c_int, [_V, C.c_int32, C.c_int32, _V, _V, _V]),
+    "inv_heads_unpack_fc1_grad": (C.c_int, [_V, _V, C.c_int32, C.c_int32, _V, _V]),
+    "inv_heads_fwd": (C.c_int, [P(InvHeadsParams), _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, _V]),
+    "inv_heads_bwd": (C.c_int, [P(InvHeadsParams), _V, _V, _V, _V, _V, _V, _V, P(InvHeadsGrads), C.c_int32, _V]),
     "inv_ppo_loss_blocks": (C.c_int32, [C.c_int32]),
     "inv_ppo_loss": (C.c_int, [_V, _V, _V, _V, _V, _V, C.c_int32, C.c_float, C.c_float, C.c_float, _V, _V, _V, _V]),
     "inv_clip_adam_workspace_bytes": (C.c_int64, []),

@@ -888,7 +888,11 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
             const int k = k0 + j;
             if (k < NIT) {
                 const int q = min(tid + k * THREADS, ITEMS - 1);     // clamped: the tail threads re-load the last item and discard it
+#ifdef POL_BWD_NO_XLOAD
+                for (int e = 0; e < 8; ++e) xc[k][e] = (bf16)(0.01f * (float)(q & 63));
+#else
                 xc[k] = reinterpret_cast<const bf16x8 *>(xhat_n)[q];
+#endif
                 const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;   // (p * COUT + part * 8) * 2
                 l0[j] = *reinterpret_cast<const f16x8 *>(lq);
                 l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
@@ -918,7 +922,9 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
                     s2 += dxh * x;
                 }
                 gc[k] = gk;
+#ifndef POL_BWD_NO_DY
                 reinterpret_cast<bf16x8 *>(dy_n)[q] = dy;
+#endif
                 *reinterpret_cast<bf16x8 *>(tp) = dy;
             }
         }
@@ -944,7 +950,9 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
             bf16x8 dz;
 #pragma unroll
             for (int e = 0; e < 8; ++e) dz[e] = (bf16)(rstd * ((float)dy[e] * (float)gc[k][e] - m1 - (float)xc[k][e] * m2));
+#ifndef POL_BWD_NO_DZ
             reinterpret_cast<bf16x8 *>(dz_n)[q] = dz;
+#endif
             *reinterpret_cast<bf16x8 *>(tp) = dz;
         }
     }
@@ -956,7 +964,11 @@ template <int CIN_T, int COUT_BELOW, int MW, int NW, bool RESIDUAL>
 __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int lane, int m0, int n0)
 {
     f32x4 acc[MW][NW];
+#ifdef POL_BWD_NO_GEMM
+    for (int mi = 0; mi < MW; ++mi) for (int i = 0; i < NW; ++i) for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.001f * (float)(lane + mi + i);
+#else
     conv_gemm<CIN_T, COUT_BELOW, MW, NW>(wt, tile, lane, m0, n0, acc);
+#endif
     const int c16 = lane & 15, kg = lane >> 4;
     if (RESIDUAL) {                                  // z4 = conv4(a3) + b4 + a3: da3 += dz4 (this lane's own entries of the tile)
 #pragma unroll
@@ -1010,6 +1022,23 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
     }
     __syncthreads();
+#ifdef POL_BWD_STAGGER
+    {
+        if (tid == 0) {
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            const uint32_t cu = ((hw >> 8) & 0xffu) | ((xcc & 15u) << 8);
+            reinterpret_cast<unsigned int *>(red)[0] = atomicAdd(&g_cu_arrivals[cu], 1u) & 1u;
+        }
+        __syncthreads();
+        const unsigned int second = reinterpret_cast<unsigned int *>(red)[0];
+        __syncthreads();
+        if (second) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)POL_BWD_STAGGER) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+#endif
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         int lane_i = lane;
         asm volatile("" : "+v"(lane_i));

@@ -15,6 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from . import heads as HD
 
 _CIN_PAD = (32, 32, 64, 128)
 
@@ -104,8 +105,12 @@ class FusedPolicy:
             self._keep += [w, b, ln]
             params.layer[i] = L.InvPolicyLayer(w.data_ptr(), b.data_ptr(), ln.data_ptr())
         self.params = params
-        # heads: first Linear of actor and critic concatenated; columns permuted from the module's
-        # flatten order (c*150 + pixel) to the kernel's channels-last order (pixel*128 + c)
+        # heads: the reference's sizes run on the fused kernels (heads.py / csrc/inv_heads.hip) ...
+        self.heads = HD.HeadsOperands(HD.head_tensors(p, self.actor_only), self.P) if HD.supported(p) else None
+        if self.heads is not None:
+            return
+        # ... any other hidden_dim keeps the torch tail: first Linear of actor and critic concatenated; columns permuted from the
+        # module's flatten order (c*150 + pixel) to the kernel's channels-last order (pixel*128 + c)
         firsts = [p.fc_actor[0]] if self.actor_only else [p.fc_actor[0], p.fc_critic[0]]
         w1 = torch.cat([m.weight for m in firsts]).detach().float()                         # [512 (256: actor only), 19204]
         hid = w1.shape[0]
@@ -147,6 +152,8 @@ class FusedPolicy:
     def __call__(self, grid, extra):
         p = self.policy
         feat = self.features(grid)
+        if self.heads is not None:
+            return self.heads.forward(feat, extra)
         h = (feat @ self.w1_feat.t()).float() + extra.float() @ self.w1_extra.t() + self.b1
         h = torch.relu(h)
         logits = p.fc_actor[4](torch.relu(p.fc_actor[2](h[:, :self.hidden])))

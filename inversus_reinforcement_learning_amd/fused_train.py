@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from .device_env import unpack_obs
+from . import heads as HD
 from .fused_policy import _CIN_PAD, _pack_conv, pack_conv, pack_ln
 
 _COUT = (32, 64, 128, 128)
@@ -188,6 +189,8 @@ class FusedTrainPolicy:
     def __call__(self, grid, extra):
         p = self.policy
         feat = self.features(grid)                                                     # bf16 [B, 19200], index pixel*128 + c
+        if HD.supported(p):
+            return HD.heads_train(p, feat, extra)                                      # fused heads (csrc/inv_heads.hip)
         extra = extra.float()
         # first Linear of both heads as ONE [512 x 19200] bf16 GEMM on the kernel's feature order (columns permuted from
         # the module's c*150 + pixel to pixel*128 + c); autograd splits the gradient back onto the two weight tensors

@@ -1,0 +1,182 @@
+"""Host side of csrc/inv_heads.hip: the two heads of InversusCNNPolicy (inversus_rl/policies.py:60-75, :102-106) after the trunk.
+
+    pre    = features @ W1[:, :128 P]^T                      the GEMM library ([B x 128 P] x [128 P x 512] bf16)
+    logits, value = inv_heads_fwd(pre, extra)                one kernel (first-layer epilogue, Linear 256 -> 128, Linear 128 -> 13 | 1)
+
+`HeadsOperands` packs a policy's head parameters for the kernels (rollouts: once per refresh); `heads_train` is the differentiable
+form the fused PPO update uses (packs per call -- the parameters change every minibatch -- and returns gradients for all 12 head
+tensors and for the features).  Only the reference's head sizes (hidden_dim = 256) have kernels; callers keep their torch tail for
+anything else."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+HID, MID, NACT = 256, 128, 13
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def supported(policy):
+    a, c = policy.fc_actor, policy.fc_critic
+    return (a[0].out_features == HID and a[2].out_features == MID and a[4].out_features == NACT and c[0].out_features == HID
+            and c[2].out_features == MID and c[4].out_features == 1)
+
+
+def _pack_fc1(weights, pixels):
+    """[256, 128 P + 4] f32 per head -> (wf bf16 [256 nheads, 128 P] in the trunk's feature order, we f32 [256 nheads, 4])."""
+    lib = L.load()
+    dev = weights[0].device
+    n = len(weights)
+    wf = torch.empty((HID * n, 128 * pixels), dtype=torch.bfloat16, device=dev)
+    we = torch.empty((HID * n, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for i, w in enumerate(weights):
+            w = w.detach()
+            if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (HID, 128 * pixels + 4):
+                raise ValueError(f"first Linear of a head must be contiguous f32 [{HID}, {128 * pixels + 4}], got {tuple(w.shape)} {w.dtype}")
+            L.raise_for(lib.inv_heads_pack_fc1(_ptr(w), HID, pixels, _ptr(wf[HID * i]), _ptr(we[HID * i]), _stream()), lib)
+    return wf, we
+
+
+def _pack_fragments(mats, need_t):
+    """mats: per head (W2 [128, 256], W3 [13 | 1, 128]) f32 -> fragment tensors {w2, w3, w2t, w3t} per head, one launch."""
+    lib = L.load()
+    dev = mats[0][0].device
+    lst, out, k = L.InvHeadsPackList(), [], 0
+    for w2, w3 in mats:
+        w2, w3 = w2.detach(), w3.detach()
+        for w, shape in ((w2, (MID, HID)), (w3, (w3.shape[0], MID))):
+            if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != shape:
+                raise ValueError(f"head Linear must be contiguous f32 {shape}, got {tuple(w.shape)} {w.dtype}")
+        d = {"w2": torch.empty(MID * HID, dtype=torch.bfloat16, device=dev), "w3": torch.empty(16 * MID, dtype=torch.bfloat16, device=dev)}
+        items = [(w2, d["w2"], MID, HID, HID, 0, MID, HID), (w3, d["w3"], w3.shape[0], MID, MID, 0, 16, MID)]
+        if need_t:
+            d["w2t"] = torch.empty(HID * MID, dtype=torch.bfloat16, device=dev)
+            d["w3t"] = torch.empty(MID * 32, dtype=torch.bfloat16, device=dev)
+            items += [(w2, d["w2t"], HID, MID, HID, 1, HID, MID), (w3, d["w3t"], MID, w3.shape[0], MID, 1, MID, 32)]
+        for src, dst, rows, cols, ld, tr, mpad, kpad in items:
+            lst.item[k] = L.InvHeadsPackItem(src.data_ptr(), dst.data_ptr(), rows, cols, ld, tr, mpad, kpad)
+            k += 1
+        out.append(d)
+    with torch.cuda.device(dev):
+        L.raise_for(lib.inv_heads_pack(C.byref(lst), k, _stream()), lib)
+    return out
+
+
+class HeadsOperands:
+    """Packed head parameters of `policy` for inv_heads_fwd / inv_heads_bwd.  nheads = 1: actor only."""
+
+    def __init__(self, heads, pixels, need_t=False):
+        """heads: per head the six tensors (W1, b1, W2, b2, W3, b3) of its nn.Sequential."""
+        self.nheads = len(heads)
+        self.wf, self.we = _pack_fc1([h[0] for h in heads], pixels)
+        self.b1 = torch.cat([h[1].detach().float() for h in heads]).contiguous()
+        frags = _pack_fragments([(h[2], h[4]) for h in heads], need_t)
+        self.keep = [frags] + [[h[3].detach().float().contiguous(), h[5].detach().float().contiguous()] for h in heads]
+        p = L.InvHeadsParams()
+        for i, (f, h) in enumerate(zip(frags, heads)):
+            p.w2[i], p.w3[i] = f["w2"].data_ptr(), f["w3"].data_ptr()
+            if need_t:
+                p.w2t[i], p.w3t[i] = f["w2t"].data_ptr(), f["w3t"].data_ptr()
+            p.b2[i], p.b3[i] = self.keep[1 + i][0].data_ptr(), self.keep[1 + i][1].data_ptr()
+        p.we, p.b1 = self.we.data_ptr(), self.b1.data_ptr()
+        self.params = p
+
+    def forward(self, feat, extra, save=False):
+        """feat bf16 [B, 128 P], extra f32 [B, 4] -> logits f32 [B, 13], value f32 [B, 1] | None (+ (pre... h, a2) when save)."""
+        lib = L.load()
+        B, n = feat.shape[0], self.nheads
+        pre = feat @ self.wf.t()                                                       # bf16 [B, 256 n], f32 accumulation
+        extra = extra.float().contiguous()
+        logits = torch.empty((B, NACT), dtype=torch.float32, device=feat.device)
+        value = torch.empty((B, 1), dtype=torch.float32, device=feat.device) if n == 2 else None
+        h = torch.empty((B, HID * n), dtype=torch.bfloat16, device=feat.device) if save else None
+        a2 = torch.empty((B, MID * n), dtype=torch.bfloat16, device=feat.device) if save else None
+        with torch.cuda.device(feat.device):
+            rc = lib.inv_heads_fwd(C.byref(self.params), _ptr(pre), _ptr(extra), _ptr(logits), _ptr(value) if n == 2 else None,
+                                   _ptr(h) if save else None, _ptr(a2) if save else None, n, B, _stream())
+        L.raise_for(rc, lib)
+        return (logits, value, extra, h, a2) if save else (logits, value)
+
+
+def head_tensors(policy, actor_only=False):
+    heads = [policy.fc_actor] if actor_only else [policy.fc_actor, policy.fc_critic]
+    return [(s[0].weight, s[0].bias, s[2].weight, s[2].bias, s[4].weight, s[4].bias) for s in heads]
+
+
+def _split_k(B):
+    for g in (32, 16, 8, 4, 2):
+        if B % g == 0 and B // g >= 64:
+            return g
+    return 1
+
+
+class _HeadsTrainFn(torch.autograd.Function):
+    """(features bf16, extra, 6 actor tensors, 6 critic tensors) -> (logits, value); gradients for everything but `extra`."""
+
+    @staticmethod
+    def forward(ctx, feat, extra, *tensors):
+        pixels = feat.shape[1] // 128
+        ops = HeadsOperands([tensors[:6], tensors[6:]], pixels, need_t=True)
+        logits, value, extra_c, h, a2 = ops.forward(feat, extra, save=True)
+        ctx.ops = ops
+        ctx.save_for_backward(feat, extra_c, h, a2)
+        ctx.pixels = pixels
+        return logits, value
+
+    @staticmethod
+    def backward(ctx, dlogits, dvalue):
+        lib = L.load()
+        feat, extra, h, a2 = ctx.saved_tensors
+        ops, P, B, dev = ctx.ops, ctx.pixels, feat.shape[0], feat.device
+        dlogits = dlogits.float().contiguous() if dlogits is not None else torch.zeros((B, NACT), dtype=torch.float32, device=dev)
+        dvalue = dvalue.float().contiguous() if dvalue is not None else torch.zeros((B, 1), dtype=torch.float32, device=dev)
+        # small gradients: one zeroed f32 buffer [db1 512 | dwe 2048 | db2 2 x 128 | dw3 13 x 128 + 128 | db3 13 + 1 (+ pad)]
+        small = torch.zeros(512 + 2048 + 256 + 14 * 128 + 16, dtype=torch.float32, device=dev)
+        o = [0, 512, 2560, 2688, 2816, 2816 + 13 * 128, 2816 + 14 * 128, 2816 + 14 * 128 + 13]
+        gr = L.InvHeadsGrads()
+        base, sz = small.data_ptr(), 4
+        gr.db1, gr.dwe = base, base + o[1] * sz
+        gr.db2[0], gr.db2[1] = base + o[2] * sz, base + o[3] * sz
+        gr.dw3[0], gr.dw3[1] = base + o[4] * sz, base + o[5] * sz
+        gr.db3[0], gr.db3[1] = base + o[6] * sz, base + o[7] * sz
+        dpre = torch.empty((B, 2 * HID), dtype=torch.bfloat16, device=dev)
+        da2 = torch.empty((B, 2 * MID), dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.inv_heads_bwd(C.byref(ops.params), _ptr(dlogits), _ptr(dvalue), _ptr(h), _ptr(a2), _ptr(extra), _ptr(dpre), _ptr(da2),
+                                   C.byref(gr), B, _stream())
+        L.raise_for(rc, lib)
+        dfeat = dpre @ ops.wf if ctx.needs_input_grad[0] else None                     # bf16 [B, 128 P]
+        dwf = dpre.t() @ feat                                                          # bf16 [512, 128 P], f32 accumulation over B
+        gw1 = []
+        with torch.cuda.device(dev):
+            for i in range(2):
+                g = torch.empty((HID, 128 * P + 4), dtype=torch.float32, device=dev)
+                L.raise_for(lib.inv_heads_unpack_fc1_grad(_ptr(dwf[HID * i]), C.c_void_p(base + (o[1] + HID * 4 * i) * sz), HID, P, _ptr(g), _stream()), lib)
+                gw1.append(g)
+        # dW2 of both heads: split-K batched product [G][256 x B/G] x [G][B/G x 512], its two diagonal blocks are the heads'
+        G = _split_k(B)
+        part = torch.bmm(da2.view(G, B // G, 2 * MID).transpose(1, 2), h.view(G, B // G, 2 * HID))       # bf16 [G, 256, 512]
+        dw2 = part.float().sum(0)
+        gw2 = [dw2[:MID, :HID].contiguous(), dw2[MID:, HID:].contiguous()]
+        db1, db2 = small[:512], small[o[2]:o[4]]
+        out = [dfeat, None]
+        for i in range(2):
+            n3 = NACT if i == 0 else 1
+            out += [gw1[i], db1[HID * i:HID * (i + 1)], gw2[i], db2[MID * i:MID * (i + 1)], small[o[4 + i]:o[4 + i] + n3 * MID].view(n3, MID),
+                    small[o[6 + i]:o[6 + i] + n3]]
+        return tuple(out)
+
+
+def heads_train(policy, feat, extra):
+    """Differentiable heads on fused kernels: (bf16 features [B, 128 P], extra [B, 4]) -> (logits [B, 13], value [B, 1])."""
+    tensors = [t for head in head_tensors(policy) for t in head]
+    return _HeadsTrainFn.apply(feat, extra, *tensors)

@@ -197,9 +197,15 @@ def test_rollout_forward_uses_the_updates_numerics_when_the_update_is_fused():
     with torch.no_grad():
         lo, v = agent.train_fwd(grid, extra)
         new_lp = torch.distributions.Categorical(logits=lo.float(), validate_args=False).log_prob(acts)
-        # identical trunk features; the heads' GEMMs run at another batch size (other tiling / summation order): ~1e-5
-        assert float((new_lp - old_lp).abs().max()) < 2e-4 and float((v.float().squeeze(-1) - old_v).abs().max()) < 2e-4
+        # identical trunk features and identical head kernels; only the library GEMM of the first Linear runs at another batch
+        # size (another tiling / summation order), which moves a bf16 rounding of `pre` here and there: mostly exact zeros
+        assert float((new_lp - old_lp).abs().max()) < 2e-3 and float((v.float().squeeze(-1) - old_v).abs().max()) < 2e-3
         assert float((new_lp - old_lp).abs().mean()) < 1e-5
+        # at the rollout's own batch size (what training uses: minibatch = num_envs) the stored numbers are reproduced exactly
+        for t in range(T):
+            lo_t, v_t = agent.train_fwd(agent.obs_grid_buffer[t], agent.obs_extra_buffer[t])
+            lp_t = torch.distributions.Categorical(logits=lo_t.float(), validate_args=False).log_prob(agent.action_buffer[t])
+            assert torch.equal(lp_t, agent.log_prob_buffer[t]) and torch.equal(v_t.float().squeeze(-1), agent.value_buffer[t])
         lo_i, _ = FusedPolicy(pol)(grid, extra)                  # inference epilogue: close, but not the same numbers
         lp_i = torch.distributions.Categorical(logits=lo_i.float(), validate_args=False).log_prob(acts)
         assert 5e-4 < float((lp_i - old_lp).abs().max()) < 0.1

@@ -108,5 +108,5 @@ def test_actor_only_opponent_gives_the_same_logits():
     full, act = FusedPolicy(pol), FusedPolicy(pol, actor_only=True)
     lf, vf = full(g, x)
     la, va = act(g, x)
-    assert va is None and vf.shape == (300, 1) and act.w1_feat.shape == (256, 19200)
+    assert va is None and vf.shape == (300, 1) and act.heads.wf.shape == (256, 19200) and full.heads.wf.shape == (512, 19200)
     assert float((lf - la).abs().max()) < 2e-3          # the same trunk features; the first Linear runs as a narrower GEMM

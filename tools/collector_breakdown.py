@@ -20,7 +20,7 @@ g, x = b.render(0)
 res = {}
 res["trunk features ms"] = t(lambda: f.features(g))
 feat = f.features(g)
-res["heads first GEMM [16384x19200]x[19200x512] bf16 ms"] = t(lambda: feat @ f.w1_feat.t())
+res["heads first GEMM [16384x19200]x[19200x512] bf16 ms"] = t(lambda: feat @ f.heads.wf.t())
 res["fused forward (trunk+heads) ms"] = t(lambda: f(g, x))
 logits, v = f(g, x)
 def sample():
