@@ -294,18 +294,22 @@ int  inv_heads_pack(const inv_heads_pack_list *list, int32_t count, void *stream
  * grad_w f32 [rows][128 P + 4], overwritten). */
 int  inv_heads_pack_fc1(const float *w, int32_t rows, int32_t pixels, void *wf_bf16, float *we, void *stream);
 int  inv_heads_unpack_fc1_grad(const void *dwf_bf16, const float *dwe, int32_t rows, int32_t pixels, float *grad_w, void *stream);
+/* bf16 [rows][cols] -> [cols][rows]: K-contiguous copies of GEMM operands (the library's NN / NT kernels are the fast ones) */
+int  inv_transpose_bf16(const void *in_bf16, int32_t rows, int32_t cols, void *out_bf16, void *stream);
 /* Forward.  nheads = 2: actor and critic (pre [B][512]); nheads = 1: actor only (pre [B][256], value may be NULL) -- the frozen
  * self-play opponent.  logits f32 [B][13], value f32 [B].  h_save bf16 [B][256 nheads] and a2_save bf16 [B][128 nheads]: both or
  * neither; what inv_heads_bwd needs.  The result for a sample does not depend on B or on its position in the batch. */
 int  inv_heads_fwd(const inv_heads_params *params, const void *pre_bf16, const float *extra, float *logits, float *value,
                    void *h_save, void *a2_save, int32_t nheads, int32_t B, void *stream);
 /* Backward (both heads).  In: dlogits f32 [B][13], dvalue f32 [B], the saved h / a2, extra f32 [B][4].  Out: dpre bf16 [B][512]
- * (= d loss / d pre, the operand of the first Linear's two backward GEMMs), da2 bf16 [B][256] (with h: the operands of
+ * (= d loss / d pre, the operand of the first Linear's two backward GEMMs), optionally (non-NULL, B % 8 == 0) its transpose
+ * dpre_t bf16 [512][B] for the weight-gradient product, da2 bf16 [B][256] (with h: the operands of
  * dW2[h] = da2[:, 128 h:128 h + 128]^T h[:, 256 h:256 h + 256]), and ADDED into the f32 buffers of `grads` (zero them first):
  * db1 [512], dwe [512][4], db2[h] [128], dw3[h] [13 | 1][128], db3[h] [13 | 1]. */
 typedef struct { float *db1, *dwe, *db2[2], *dw3[2], *db3[2]; } inv_heads_grads;
 int  inv_heads_bwd(const inv_heads_params *params, const float *dlogits, const float *dvalue, const void *h, const void *a2,
-                   const float *extra, void *dpre_bf16, void *da2_bf16, const inv_heads_grads *grads, int32_t B, void *stream);
+                   const float *extra, void *dpre_bf16, void *dpre_t_bf16, void *da2_bf16, const inv_heads_grads *grads, int32_t B,
+                   void *stream);
 
 /* ---- the scalar tail of the PPO update ------------------------------------------------------
  * inv_ppo_loss: forward AND backward of the reference's minibatch loss (inversus_rl/ppo_agent.py:211-224)

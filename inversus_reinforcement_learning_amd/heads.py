@@ -149,13 +149,20 @@ class _HeadsTrainFn(torch.autograd.Function):
         gr.dw3[0], gr.dw3[1] = base + o[4] * sz, base + o[5] * sz
         gr.db3[0], gr.db3[1] = base + o[6] * sz, base + o[7] * sz
         dpre = torch.empty((B, 2 * HID), dtype=torch.bfloat16, device=dev)
+        dpre_t = torch.empty((2 * HID, B), dtype=torch.bfloat16, device=dev) if B % 8 == 0 else None
         da2 = torch.empty((B, 2 * MID), dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.inv_heads_bwd(C.byref(ops.params), _ptr(dlogits), _ptr(dvalue), _ptr(h), _ptr(a2), _ptr(extra), _ptr(dpre), _ptr(da2),
-                                   C.byref(gr), B, _stream())
+            rc = lib.inv_heads_bwd(C.byref(ops.params), _ptr(dlogits), _ptr(dvalue), _ptr(h), _ptr(a2), _ptr(extra), _ptr(dpre),
+                                   _ptr(dpre_t) if dpre_t is not None else None, _ptr(da2), C.byref(gr), B, _stream())
         L.raise_for(rc, lib)
-        dfeat = dpre @ ops.wf if ctx.needs_input_grad[0] else None                     # bf16 [B, 128 P]
-        dwf = dpre.t() @ feat                                                          # bf16 [512, 128 P], f32 accumulation over B
+        # the library's kernels for K-contiguous operands are the fast ones (tools/fc1_gemm_ab.py): both products get a transposed copy
+        dfeat = None
+        if ctx.needs_input_grad[0]:
+            wft = torch.empty((128 * P, 2 * HID), dtype=torch.bfloat16, device=dev)
+            with torch.cuda.device(dev):
+                L.raise_for(lib.inv_transpose_bf16(_ptr(ops.wf), 2 * HID, 128 * P, _ptr(wft), _stream()), lib)
+            dfeat = dpre @ wft.t()                                                     # bf16 [B, 128 P]
+        dwf = (dpre_t if dpre_t is not None else dpre.t()) @ feat                      # bf16 [512, 128 P], f32 accumulation over B
         gw1 = []
         with torch.cuda.device(dev):
             for i in range(2):

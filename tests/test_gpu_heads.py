@@ -152,8 +152,19 @@ def test_ragged_batch_leaves_rows_past_b_untouched_and_adds_into_the_gradient_bu
     gr.db3[0], gr.db3[1] = b + 4608 * 4, b + 4621 * 4
     dpre = torch.full((n + 8, 512), 7.0, dtype=torch.bfloat16, device="cuda"); da2 = torch.full((n + 8, 256), 7.0, dtype=torch.bfloat16, device="cuda")
     rc = lib.inv_heads_bwd(C.byref(ops.params), C.c_void_p(dl.data_ptr()), C.c_void_p(dv.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(a2.data_ptr()),
-                           C.c_void_p(ex.data_ptr()), C.c_void_p(dpre.data_ptr()), C.c_void_p(da2.data_ptr()), C.byref(gr), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                           C.c_void_p(ex.data_ptr()), C.c_void_p(dpre.data_ptr()), None, C.c_void_p(da2.data_ptr()), C.byref(gr), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     L.raise_for(rc, lib)
+    # d pre^T (B % 8 == 0 only): the same numbers, transposed; a ragged last tile writes only its own columns
+    n8 = 40
+    dpre8 = torch.full((n8, 512), 7.0, dtype=torch.bfloat16, device="cuda"); dpt = torch.full((512, n8), 7.0, dtype=torch.bfloat16, device="cuda")
+    args = lambda nn, t: (C.byref(ops.params), C.c_void_p(dl.data_ptr()), C.c_void_p(dv.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(a2.data_ptr()),
+                          C.c_void_p(ex.data_ptr()), C.c_void_p(dpre8.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(da2.data_ptr()), C.byref(gr), nn,
+                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    saved_small = small.clone()
+    L.raise_for(lib.inv_heads_bwd(*args(n8, dpt)), lib)
+    assert torch.equal(dpt, dpre8.t()) and torch.equal(dpre8, dpre[:n8])
+    assert lib.inv_heads_bwd(*args(n, dpt)) == L.INV_ERR_BAD_ARG                 # 45 % 8 != 0
+    small.copy_(saved_small)
     assert bool((dpre[n:] == 7).all()) and bool((da2[n:] == 7).all())
     # d b2 = column sums of d a2, d b1 = column sums of d pre, on top of the 1.0 that was there
     assert torch.allclose(small[2560:2816] - 1.0, da2[:n].float().sum(0), rtol=1e-4, atol=1e-4)
@@ -179,6 +190,10 @@ def test_pack_fc1_and_its_gradient_are_inverse_permutations():
     L.raise_for(lib.inv_heads_unpack_fc1_grad(C.c_void_p(wf.data_ptr()), C.c_void_p(we.data_ptr()), 256, 150, C.c_void_p(g.data_ptr()),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), lib)
     assert torch.equal(g[:, :19200], w[:, :19200].to(torch.bfloat16).float()) and torch.equal(g[:, 19200:], w[:, 19200:])
+    for rows, cols in ((256, 19200), (70, 130)):
+        src = torch.randn(rows, cols, device="cuda").to(torch.bfloat16); dst = torch.empty((cols, rows), dtype=torch.bfloat16, device="cuda")
+        L.raise_for(lib.inv_transpose_bf16(C.c_void_p(src.data_ptr()), rows, cols, C.c_void_p(dst.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), lib)
+        assert torch.equal(dst, src.t())
 
 
 def test_bad_arguments_are_refused():
