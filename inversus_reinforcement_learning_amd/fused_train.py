@@ -163,6 +163,18 @@ class _TrunkTrainFn(torch.autograd.Function):
         return tuple(out)
 
 
+class _DirectCtx:
+    """Stand-in for the autograd context when a Function's forward / backward are called directly (loss_and_grads)."""
+    needs_input_grad = (True,) * 32
+    saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
 def _trunk_params(p):
     out = []
     for conv, norm in ((p.conv1, p.norm1), (p.conv2, p.norm2), (p.conv3, p.norm3), (p.conv4, p.norm4)):
@@ -185,6 +197,41 @@ class FusedTrainPolicy:
 
     def features(self, grid):
         return _TrunkTrainFn.apply(grid, *_trunk_params(self.policy))
+
+    @torch.no_grad()
+    def loss_and_grads(self, grid, extra, actions, old_log_probs, advantages, returns, clip_ratio, value_coef, entropy_coef,
+                       after_heads=None):
+        """One minibatch of the PPO loss (ppo_agent.py:206-225) forward AND backward without the autograd engine: the same kernels
+        in the same order as `loss.backward()` over __call__ + flat_optim.ppo_loss, but every parameter's gradient is COPIED into
+        its existing .grad (the slices of the flat gradient bucket) by two multi-tensor copies instead of 28 accumulate kernels
+        over a zeroed bucket.  after_heads(): called once the heads' gradients are in place (the reducer starts their all-reduce
+        while the trunk's backward runs).  -> means f32 [3] = policy loss, value loss, entropy."""
+        from .flat_optim import _PPOLossFn
+        p = self.policy
+        if not HD.supported(p):
+            raise ValueError("loss_and_grads needs the reference's head sizes (hidden_dim = 256)")
+        tparams, hparams = _trunk_params(p), [t for h in HD.head_tensors(p) for t in h]
+        if any(q.grad is None for q in tparams + hparams):
+            raise RuntimeError("loss_and_grads writes into existing .grad tensors (FlatAdam / FlatGradReducer create them)")
+        tctx, hctx, lctx = _DirectCtx(), _DirectCtx(), _DirectCtx()
+        feat = _TrunkTrainFn.forward(tctx, grid, *tparams)
+        logits, value = HD._HeadsTrainFn.forward(hctx, feat, extra, *hparams)
+        if actions.dtype != torch.int64:
+            actions = actions.to(torch.int64)
+        _, means = _PPOLossFn.forward(lctx, logits, value.squeeze(-1), actions, old_log_probs, advantages, returns,
+                                      clip_ratio, value_coef, entropy_coef)
+        dlogits, dvalues = lctx.saved_tensors                             # d loss / d logits, d values (loss.backward(): g_loss = 1)
+        w1 = (hparams[0], hparams[6])                                     # 39.3 of the 41 MB: written in place by the unpack kernel
+        if all(q.grad.is_contiguous() for q in w1):
+            hctx.fc1_grad_out = [q.grad for q in w1]
+        hg = HD._HeadsTrainFn.backward(hctx, dlogits, dvalues.reshape(-1, 1))
+        pairs = [(q.grad, g) for q, g in zip(hparams, hg[2:]) if g is not q.grad]
+        torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
+        if after_heads is not None:
+            after_heads()
+        tg = _TrunkTrainFn.backward(tctx, hg[0])
+        torch._foreach_copy_([q.grad for q in tparams], list(tg[1:]))
+        return means
 
     def __call__(self, grid, extra):
         p = self.policy

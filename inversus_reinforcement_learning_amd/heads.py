@@ -166,7 +166,8 @@ class _HeadsTrainFn(torch.autograd.Function):
         gw1 = []
         with torch.cuda.device(dev):
             for i in range(2):
-                g = torch.empty((HID, 128 * P + 4), dtype=torch.float32, device=dev)
+                dst = getattr(ctx, "fc1_grad_out", None)                              # direct path: the parameter's .grad itself
+                g = dst[i] if dst is not None else torch.empty((HID, 128 * P + 4), dtype=torch.float32, device=dev)
                 L.raise_for(lib.inv_heads_unpack_fc1_grad(_ptr(dwf[HID * i]), C.c_void_p(base + (o[1] + HID * 4 * i) * sz), HID, P, _ptr(g), _stream()), lib)
                 gw1.append(g)
         # dW2 of both heads: split-K batched product [G][256 x B/G] x [G][B/G x 512], its two diagonal blocks are the heads'

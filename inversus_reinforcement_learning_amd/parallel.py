@@ -100,6 +100,12 @@ class FlatGradReducer:
         if self._pending == 0 and self._work is None:
             self._work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
 
+    def start_early(self):
+        """The `early` parameters' gradients are final (written without the autograd engine, so no hook fired): launch their
+        all-reduce now; reduce() waits for it."""
+        if initialized() and self.n_early and self._work is None:
+            self._work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
+
     def zero(self):
         """Zero the gradients.  Always use this instead of optimizer.zero_grad() / module.zero_grad(): those default to
         set_to_none=True, which detaches the parameters' .grad from the bucket (reduce() repairs and reports that)."""

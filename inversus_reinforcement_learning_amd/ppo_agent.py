@@ -56,6 +56,13 @@ class PPOAgent:
             order = self.reducer.params if self.reducer is not None else [p for p in self.policy.parameters() if p.requires_grad]
             self.flat_adam = FlatAdam(order, lr=lr, max_grad_norm=max_grad_norm,
                                       grad_flat=self.reducer.flat if self.reducer is not None else None)
+        # every parameter gets its gradient from the fused kernels: the update then bypasses the autograd engine (loss_and_grads)
+        self.direct_grads = False
+        if fused_update:
+            from . import heads as HD
+            from .fused_train import _trunk_params
+            covered = {id(q) for q in _trunk_params(self.policy)} | {id(t) for h in HD.head_tensors(self.policy) for t in h}
+            self.direct_grads = HD.supported(self.policy) and covered == {id(q) for q in self.flat_adam.params}
         self.fused = None
         if fused_act:
             from .fused_policy import FusedPolicy
@@ -187,6 +194,25 @@ class PPOAgent:
                     raise ValueError(f"permutations[{epoch}] must index all {num_samples} samples")
             for start in range(0, num_samples, self.batch_size):
                 idx = indices[start:start + self.batch_size]
+                if self.direct_grads:
+                    # fused trunk / heads / loss kernels forward and backward without the autograd engine; every gradient is
+                    # written into the flat bucket (nothing to zero), the heads' all-reduce starts before the trunk's backward
+                    means = self.train_fwd.loss_and_grads(obs_grid[idx], obs_extra[idx], actions[idx], old_log_probs[idx], advantages[idx],
+                                                          returns[idx], self.clip_ratio, self.value_coef, self.entropy_coef,
+                                                          after_heads=self.reducer.start_early if self.reducer is not None else None)
+                    if self.reducer is not None:
+                        self.reducer.reduce(average=False)                # SUM over ranks; the 1/world_size rides in the Adam kernel
+                        grad_norm = self.flat_adam.step(grad_scale=1.0 / parallel.world()[1])
+                    else:
+                        grad_norm = self.flat_adam.step()
+                    policy_loss, value_loss, entropy = means[0], means[1], means[2]
+                    if trace:
+                        mb_trace.append(torch.stack([policy_loss, value_loss, entropy, grad_norm.detach()]))
+                    tot_p += policy_loss
+                    tot_v += value_loss
+                    tot_e += entropy
+                    num_updates += 1
+                    continue
                 if self.train_fwd is not None:                            # fused trunk kernels; reads packed observations as is
                     logits, values = self.train_fwd(obs_grid[idx], obs_extra[idx])
                 else:

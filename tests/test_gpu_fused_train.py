@@ -240,3 +240,36 @@ def test_pack_kernels_equal_the_torch_index_arithmetic():
         L.raise_for(lib.inv_policy_obs_to_x0(C.c_void_p(src.data_ptr()), is_bits, C.c_void_p(x0.data_ptr()), n,
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), lib)
         assert torch.equal(x0, want)
+
+
+def test_direct_gradients_equal_the_autograd_path():
+    """FusedTrainPolicy.loss_and_grads (no autograd engine, gradients copied into the flat bucket) against loss.backward() over
+    the same kernels: the same numbers up to the f32 atomics of the weight-gradient kernels."""
+    import torch
+    from inversus_reinforcement_learning_amd.flat_optim import ppo_loss
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    n = 700
+    pol = _policy(7)
+    agent = PPOAgent(pol, fused_act=True, fused_update=True, batch_size=n, epochs=1)
+    assert agent.direct_grads
+    gf, gb, x = _obs(n, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = torch.randint(0, 13, (n,), device="cuda", generator=g)
+    old_lp = -2.5 + 0.1 * torch.randn(n, device="cuda", generator=g)
+    adv, ret = torch.randn(n, device="cuda", generator=g), torch.randn(n, device="cuda", generator=g)
+    flat = agent.flat_adam.grad
+    flat.fill_(123.0)                                                     # the direct path overwrites every slot
+    means_d = agent.train_fwd.loss_and_grads(gb, x, acts, old_lp, adv, ret, 0.2, 0.1, 0.02)
+    direct = flat.clone()
+    assert bool(torch.isfinite(direct).all()) and not bool((direct == 123.0).any())
+    flat.zero_()
+    lo, v = agent.train_fwd(gb, x)
+    loss, means_a = ppo_loss(lo.float(), v.float().squeeze(-1), acts, old_lp, adv, ret, 0.2, 0.1, 0.02)
+    loss.backward()
+    agent.flat_adam._check_aliases()
+    assert torch.equal(means_d, means_a)
+    off = 0
+    for q in agent.flat_adam.params:
+        a, b = direct[off:off + q.numel()], flat[off:off + q.numel()]
+        assert rel(a, b) < 1e-5, (tuple(q.shape), rel(a, b))
+        off += q.numel()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """PPOAgent(fused_act, fused_update).update() at B = 16384 per minibatch: ms per minibatch, kernel launches per minibatch and the
-top GPU kernels (torch.profiler).  Usage: python tools/agent_update_profile.py [--no-prof]"""
+top GPU kernels (torch.profiler).  Usage: python tools/agent_update_profile.py [--no-prof] [--autograd]"""
 import os, sys, json, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,8 @@ n, T = 16384, 4
 torch.manual_seed(0)
 b = DeviceEnvBatch(n, opponent="selfplay"); b.seed(np.arange(n, dtype=np.int64)); b.reset()
 agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), fused_act=True, fused_update=True, batch_size=n, epochs=1)
+if "--autograd" in sys.argv:
+    agent.direct_grads = False          # loss.backward() over the same kernels instead of FusedTrainPolicy.loss_and_grads
 col = RolloutCollector(b, agent, FusedPolicy(InversusCNNPolicy(12, 10, 15, 4).cuda().eval()))
 def once():
     col.collect(T); torch.cuda.synchronize(); t0 = time.perf_counter(); agent.update(); torch.cuda.synchronize()
