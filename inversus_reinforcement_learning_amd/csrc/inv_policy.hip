@@ -866,55 +866,94 @@ __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int l
 // the tile and HBM -> transposed implicit GEMM on the tile -> da' (bf16) back into the tile.
 
 // pass A + B of one layer.  FROM_GLOBAL: da comes from HBM (layer 4: dfeat) instead of the tile.
-template <int COUT, bool FROM_GLOBAL>
-__device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf16 *xhat_n, float rstd, const bf16 *da_n, bf16 *dy_n, bf16 *dz_n,
-                                                 bf16 *tile, float *red)
+// items (pixel, 8 channels) per thread of a layer with COUT channels; CH of them are in flight at once (12-16 registers each)
+template <int COUT> struct BwdItems {
+    static constexpr int ITEMS = P * (COUT / 8), NIT = (ITEMS + THREADS - 1) / THREADS, CH = NIT < 5 ? NIT : 5;
+};
+
+// Registers of pass A that can be requested before the pass starts: x^ of all the thread's items (the first CH requested) and the
+// two LayerNorm parameter buffers of the batch pipeline.
+template <int COUT> struct BwdRegs {
+    bf16x8 xc[BwdItems<COUT>::NIT];
+    f16x8 l0[2][BwdItems<COUT>::CH], l1[2][BwdItems<COUT>::CH];
+};
+
+// The global loads of batch `bt` of a layer's pass A (x^ from HBM, LayerNorm parameters from L2).
+template <int COUT>
+__device__ __forceinline__ void bwd_request(BwdRegs<COUT> &rg, int bt, const void *ln_packed, const bf16 *xhat_n)
 {
-    // A thread owns the same NIT items (pixel, 8 channels) in both passes.  All of a pass's global loads are requested before
-    // the first one is used (one L2 / HBM round trip per pass instead of one per item), and pass B re-uses the x^ and LayerNorm
-    // weights that pass A fetched (80 registers at COUT = 128; the GEMM's registers are dead here) instead of loading them again.
-    constexpr int CH8 = COUT / 8, ITEMS = P * CH8, NIT = (ITEMS + THREADS - 1) / THREADS;
+    constexpr int ITEMS = BwdItems<COUT>::ITEMS, NIT = BwdItems<COUT>::NIT, CH = BwdItems<COUT>::CH;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int k = bt * CH + j;
+        if (k < NIT) {
+            const int q = min((int)threadIdx.x + k * THREADS, ITEMS - 1);     // clamped: the tail threads re-load the last item and discard it
+#ifdef POL_BWD_NO_XLOAD
+            for (int e = 0; e < 8; ++e) rg.xc[k][e] = (bf16)(0.01f * (float)(q & 63));
+#else
+            rg.xc[k] = reinterpret_cast<const bf16x8 *>(xhat_n)[q];
+#endif
+            const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;   // (p * COUT + part * 8) * 2
+            rg.l0[bt & 1][j] = *reinterpret_cast<const f16x8 *>(lq);
+            rg.l1[bt & 1][j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+        }
+    }
+}
+
+// REQUESTED (POL_BWD_EARLY, off): batch 0 was requested by the caller from the epilogue of the transposed convolution above this
+// pass, after its last weight-fragment wait, so that the HBM round trip overlaps the accumulator write-back and its two barriers.
+// Measured 1.89 vs 1.85-1.87 ms without: the other workgroup of the CU already fills that gap.
+#ifndef POL_BWD_EARLY
+#define POL_BWD_EARLY 0
+#endif
+template <int COUT, bool FROM_GLOBAL, bool REQUESTED = false>
+__device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf16 *xhat_n, float rstd, const bf16 *da_n, bf16 *dy_n, bf16 *dz_n,
+                                                 bf16 *tile, float *red, BwdRegs<COUT> &rg)
+{
+    // A thread owns the same NIT items (pixel, 8 channels) in both passes.  Pass A is a two-stage pipeline over batches of CH
+    // items: the global loads of batch b + 1 (x^, LayerNorm parameters, and da for the top layer) are requested before batch b
+    // is consumed, and pass B re-uses the x^ and LayerNorm weights that pass A fetched (80 registers at COUT = 128; the GEMM's
+    // registers are dead here) instead of loading them again.  (Requesting x^ even earlier, before the transposed convolution
+    // that produces da, does not help: vmcnt retires in order, so the GEMM's first weight-fragment wait then also waits for the
+    // HBM loads issued before it -- and 20-40 more live registers put the 2 x 10-tile GEMM into scratch: 2.45-2.70 vs 1.90 ms.)
+    constexpr int CH8 = COUT / 8, ITEMS = BwdItems<COUT>::ITEMS, NIT = BwdItems<COUT>::NIT, CH = BwdItems<COUT>::CH;
+    constexpr int NB = (NIT + CH - 1) / CH;
     const int tid = threadIdx.x;
-    bf16x8 xc[NIT];                                      // x^ of the thread's items
+    bf16x8 (&xc)[NIT] = rg.xc;                           // x^ of the thread's items
+    f16x8 (&l0)[2][CH] = rg.l0, (&l1)[2][CH] = rg.l1;
     f16x8 gc[NIT];                                       // their 8 LayerNorm weights
     float s1 = 0.0f, s2 = 0.0f;
-    constexpr int CH = NIT < 5 ? NIT : 5;                // items in flight at once (12-16 registers each)
+    bf16x8 dag[2][FROM_GLOBAL ? CH : 1];
+    auto request = [&](int bt) {
+        bwd_request<COUT>(rg, bt, ln_packed, xhat_n);
+        if (FROM_GLOBAL) {
 #pragma unroll
-    for (int k0 = 0; k0 < NIT; k0 += CH) {
-        f16x8 l0[CH], l1[CH];
-        bf16x8 dag[FROM_GLOBAL ? CH : 1];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int k = k0 + j;
-            if (k < NIT) {
-                const int q = min(tid + k * THREADS, ITEMS - 1);     // clamped: the tail threads re-load the last item and discard it
-#ifdef POL_BWD_NO_XLOAD
-                for (int e = 0; e < 8; ++e) xc[k][e] = (bf16)(0.01f * (float)(q & 63));
-#else
-                xc[k] = reinterpret_cast<const bf16x8 *>(xhat_n)[q];
-#endif
-                const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;   // (p * COUT + part * 8) * 2
-                l0[j] = *reinterpret_cast<const f16x8 *>(lq);
-                l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
-                if (FROM_GLOBAL) dag[j] = reinterpret_cast<const bf16x8 *>(da_n)[q];
+            for (int j = 0; j < CH; ++j) {
+                const int k = bt * CH + j;
+                if (k < NIT) dag[bt & 1][j] = reinterpret_cast<const bf16x8 *>(da_n)[min(tid + k * THREADS, ITEMS - 1)];
             }
         }
+    };
+    if (!REQUESTED) request(0);
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+        if (bt + 1 < NB) request(bt + 1);
         POL_PIN();
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int k = k0 + j, q = tid + k * THREADS;
+            const int k = bt * CH + j, q = tid + k * THREADS;
             if (k < NIT && q < ITEMS) {
                 const int p = q / CH8, part = q - p * CH8;
                 bf16 *tp = tile + pos_of(p) * CSF + part * 8;
-                const bf16x8 da = FROM_GLOBAL ? dag[FROM_GLOBAL ? j : 0] : *reinterpret_cast<const bf16x8 *>(tp);
+                const bf16x8 da = FROM_GLOBAL ? dag[bt & 1][FROM_GLOBAL ? j : 0] : *reinterpret_cast<const bf16x8 *>(tp);
                 const bf16x8 xh = xc[k];
                 bf16x8 dy;
                 f16x8 gk;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const _Float16 gh = e < 4 ? l0[j][e] : l1[j][e - 4];
+                    const _Float16 gh = e < 4 ? l0[bt & 1][j][e] : l1[bt & 1][j][e - 4];
                     gk[e] = gh;
-                    const float x = (float)xh[e], g = (float)gh, bb = (float)(e < 4 ? l0[j][4 + e] : l1[j][e]);
+                    const float x = (float)xh[e], g = (float)gh, bb = (float)(e < 4 ? l0[bt & 1][j][4 + e] : l1[bt & 1][j][e]);
                     const float d = fmaf(x, g, bb) > 0.0f ? (float)da[e] : 0.0f;
                     dy[e] = (bf16)d;
                     const float dxh = (float)dy[e] * g;  // from the ROUNDED dy: pass B recomputes exactly this value
@@ -961,13 +1000,18 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
 
 // transposed conv of the dz tile -> da of the layer below, written back into the tile as bf16 (channels 0 .. COUT_BELOW)
 template <int CIN_T, int COUT_BELOW, int MW, int NW, bool RESIDUAL>
-__device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int lane, int m0, int n0)
+__device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int lane, int m0, int n0, BwdRegs<COUT_BELOW> &next, const void *next_ln,
+                                               const bf16 *next_xhat)
 {
     f32x4 acc[MW][NW];
 #ifdef POL_BWD_NO_GEMM
     for (int mi = 0; mi < MW; ++mi) for (int i = 0; i < NW; ++i) for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.001f * (float)(lane + mi + i);
 #else
     conv_gemm<CIN_T, COUT_BELOW, MW, NW>(wt, tile, lane, m0, n0, acc);
+#endif
+#if POL_BWD_EARLY
+    bwd_request<COUT_BELOW>(next, 0, next_ln, next_xhat);      // the GEMM's fragment registers are dead: first batch of the pass below
+    POL_PIN();
 #endif
     const int c16 = lane & 15, kg = lane >> 4;
     if (RESIDUAL) {                                  // z4 = conv4(a3) + b4 + a3: da3 += dz4 (this lane's own entries of the tile)
@@ -1022,43 +1066,32 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
     }
     __syncthreads();
-#ifdef POL_BWD_STAGGER
-    {
-        if (tid == 0) {
-            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-            const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-            const uint32_t cu = ((hw >> 8) & 0xffu) | ((xcc & 15u) << 8);
-            reinterpret_cast<unsigned int *>(red)[0] = atomicAdd(&g_cu_arrivals[cu], 1u) & 1u;
-        }
-        __syncthreads();
-        const unsigned int second = reinterpret_cast<unsigned int *>(red)[0];
-        __syncthreads();
-        if (second) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)POL_BWD_STAGGER) __builtin_amdgcn_s_sleep(32);
-        }
-    }
-#endif
+    constexpr bool EARLY = POL_BWD_EARLY != 0;
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         int lane_i = lane;
         asm volatile("" : "+v"(lane_i));
         const size_t sn = (size_t)n * P;
         const float4 rs = *reinterpret_cast<const float4 *>(sv.rstd + (size_t)n * 4);
-        ln_relu_bwd_rows<128, true>(prm.ln[3], reinterpret_cast<const bf16 *>(sv.xhat[3]) + sn * 128, rs.w, dfeat + sn * 128,
-                                    reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red);
+        const bf16 *xh3 = reinterpret_cast<const bf16 *>(sv.xhat[3]) + sn * 128, *xh2 = reinterpret_cast<const bf16 *>(sv.xhat[2]) + sn * 128;
+        const bf16 *xh1 = reinterpret_cast<const bf16 *>(sv.xhat[1]) + sn * 64, *xh0 = reinterpret_cast<const bf16 *>(sv.xhat[0]) + sn * 32;
+        BwdRegs<128> ra;
+        BwdRegs<64> rb;
+        BwdRegs<32> rc;
+        ln_relu_bwd_rows<128, true>(prm.ln[3], xh3, rs.w, dfeat + sn * 128, reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128,
+                                    reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red, ra);
 #if POL_ROWTILES
-        conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0);
+        conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0, ra, prm.ln[2], xh2);
 #else
-        conv_t_to_tile<128, 128, 4, 5, true>(prm.wt[2], tile, lane_i, (wave & 1) * 4, (wave >> 1) * 5);
+        conv_t_to_tile<128, 128, 4, 5, true>(prm.wt[2], tile, lane_i, (wave & 1) * 4, (wave >> 1) * 5, ra, prm.ln[2], xh2);
 #endif
-        ln_relu_bwd_rows<128, false>(prm.ln[2], reinterpret_cast<const bf16 *>(sv.xhat[2]) + sn * 128, rs.z, nullptr,
-                                     reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128, reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128, tile, red);
-        conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0);
-        ln_relu_bwd_rows<64, false>(prm.ln[1], reinterpret_cast<const bf16 *>(sv.xhat[1]) + sn * 64, rs.y, nullptr,
-                                    reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64, reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64, tile, red);
-        conv_t_to_tile<64, 32, 1, 5, false>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5);
-        ln_relu_bwd_rows<32, false>(prm.ln[0], reinterpret_cast<const bf16 *>(sv.xhat[0]) + sn * 32, rs.x, nullptr,
-                                    reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32, reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32, tile, red);
+        ln_relu_bwd_rows<128, false, EARLY>(prm.ln[2], xh2, rs.z, nullptr, reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128,
+                                            reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128, tile, red, ra);
+        conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0, rb, prm.ln[1], xh1);
+        ln_relu_bwd_rows<64, false, EARLY>(prm.ln[1], xh1, rs.y, nullptr, reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64,
+                                           reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64, tile, red, rb);
+        conv_t_to_tile<64, 32, 1, 5, false>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5, rc, prm.ln[0], xh0);
+        ln_relu_bwd_rows<32, false, EARLY>(prm.ln[0], xh0, rs.x, nullptr, reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32,
+                                           reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32, tile, red, rc);
     }
 }
 
