@@ -265,9 +265,12 @@ def side_measurements(torch, np, n):
             # warm-up with the SAME number of steps: the rollout buffer keeps every step's observations alive, so a shorter
             # warm-up leaves hipMalloc calls of 118 MB blocks inside the timed region (the f32 variant read 1.3 M instead of 4.8 M)
             col.collect(8); agent.reset_buffers(); torch.cuda.synchronize()
-            t0 = time.perf_counter(); col.collect(8); torch.cuda.synchronize()
-            res[key] = round(8 * n / (time.perf_counter() - t0))
-            agent.reset_buffers()
+            rates = []
+            for _ in range(3):                                   # median of 3: the first timed collect after a (re)build reads 5-7 % low
+                t0 = time.perf_counter(); col.collect(8); torch.cuda.synchronize()
+                rates.append(round(8 * n / (time.perf_counter() - t0)))
+                agent.reset_buffers()
+            res[key] = sorted(rates)[1]
         return res
     guard("policy in the loop (selfplay, fused bf16 trunk, 2 forwards/step)", policy_cfg)
 

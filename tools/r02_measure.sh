@@ -22,9 +22,9 @@ export DIFF=hard; rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS
 python3 tools/pmc_summary.py k_step $O/pmc_s2/*/*counter_collection.csv > $O/pmc_sq_k_step4_hard.txt 2>&1
 export INVERSUS_STEP_KERNEL=wave DIFF=hard; rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $O/pmc_s3 -- python3 tools/prof_step.py > /dev/null 2> $O/pmc_s3.err; unset INVERSUS_STEP_KERNEL DIFF
 python3 tools/pmc_summary.py k_step $O/pmc_s3/*/*counter_collection.csv > $O/pmc_sq_k_step_wave_hard.txt 2>&1
-pmc p1 tools/prof_policy.py SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+export REPS=12; pmc p1 tools/prof_policy.py SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES SQ_WAVE_CYCLES
 pmc p2 tools/prof_policy.py SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS
-python3 tools/pmc_summary.py k_policy_trunk $O/pmc_p1/*/*counter_collection.csv $O/pmc_p2/*/*counter_collection.csv > $O/policy_trunk_pmc.txt 2>&1
+unset REPS; python3 tools/pmc_summary.py k_policy_trunk $O/pmc_p1/*/*counter_collection.csv $O/pmc_p2/*/*counter_collection.csv > $O/policy_trunk_pmc.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_pol -- python3 tools/prof_policy.py > /dev/null 2> $O/kt_pol.err
 find $O/kt_pol -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/policy_trunk_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_upd -- python3 tools/agent_update_profile.py --no-prof > $O/update_under_rocprof.json 2> $O/kt_upd.err
