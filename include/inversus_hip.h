@@ -322,6 +322,14 @@ int32_t inv_ppo_loss_blocks(int32_t B);
 int  inv_ppo_loss(const float *logits, const float *values, const int64_t *actions, const float *old_log_probs,
                   const float *advantages, const float *returns, int32_t B, float clip_ratio, float value_coef,
                   float entropy_coef, float *dlogits, float *dvalues, float *partial_sums, void *stream);
+/* inv_sample_actions: Categorical(logits).sample() and .log_prob(sample) of PPOAgent.act (inversus_rl/ppo_agent.py:96-100) for B
+ * samples of 13 logits, one kernel.  The log-softmax uses the expressions of inv_ppo_loss, so the update's ratio
+ * exp(new_logp - old_logp) is exactly 1 on identical logits.  Sampling: inverse CDF at one Philox4x32-10 uniform per sample,
+ * counter = sample index, key / counter words from seed[0..1] (two int64 in DEVICE memory -- e.g. drawn from the framework's
+ * generator, so that its seeding controls the stream without a host round trip).  Outputs (each may be NULL, at least one action
+ * form required): actions int64 [B], actions_u8 uint8 [B] (the form inv_step reads), log_prob f32 [B]. */
+int  inv_sample_actions(const float *logits, int32_t B, const int64_t *seed, int64_t *actions, uint8_t *actions_u8, float *log_prob,
+                        void *stream);
 /* inv_clip_adam_step: torch.nn.utils.clip_grad_norm_(params, max_grad_norm) followed by torch.optim.Adam.step()
  * (ppo_agent.py:227-232; no weight decay, no amsgrad) over ONE flat f32 buffer of n parameters with its gradient and
  * moment buffers (16-byte aligned), two launches, no host synchronisation:

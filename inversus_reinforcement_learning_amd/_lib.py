@@ -126,6 +126,7 @@ SIGNATURES = {
     "inv_transpose_bf16": (C.c_int, [_V, C.c_int32, C.c_int32, _V, _V]),
     "inv_ppo_loss_blocks": (C.c_int32, [C.c_int32]),
     "inv_ppo_loss": (C.c_int, [_V, _V, _V, _V, _V, _V, C.c_int32, C.c_float, C.c_float, C.c_float, _V, _V, _V, _V]),
+    "inv_sample_actions": (C.c_int, [_V, C.c_int32, _V, _V, _V, _V, _V]),
     "inv_clip_adam_workspace_bytes": (C.c_int64, []),
     "inv_clip_adam_step": (C.c_int, [_V, _V, _V, _V, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float,
                                      C.c_float, _V, _V]),

@@ -61,6 +61,26 @@ def ppo_loss(logits, values, actions, old_log_probs, advantages, returns, clip_r
     return _PPOLossFn.apply(logits, values, actions, old_log_probs, advantages, returns, clip_ratio, value_coef, entropy_coef)
 
 
+def sample_actions(logits, want_log_prob=True, want_i64=True, want_u8=False):
+    """Categorical(logits=logits).sample() [+ .log_prob] as one kernel (csrc/inv_optim.hip: k_sample_actions).  The Philox key comes
+    from torch's device generator (one tiny launch), so torch.manual_seed controls the stream.
+    -> (actions int64 [B] | None, actions uint8 [B] | None, log_prob f32 [B] | None)."""
+    lib = L.load()
+    logits = logits.detach().float().contiguous()
+    b, dev = logits.shape[0], logits.device
+    if logits.dim() != 2 or logits.shape[1] != 13:
+        raise ValueError(f"sample_actions expects logits [B, 13], got {tuple(logits.shape)}")
+    seed = torch.randint(-2 ** 62, 2 ** 62, (2,), dtype=torch.int64, device=dev)
+    a64 = torch.empty(b, dtype=torch.int64, device=dev) if want_i64 else None
+    a8 = torch.empty(b, dtype=torch.uint8, device=dev) if want_u8 else None
+    lp = torch.empty(b, dtype=torch.float32, device=dev) if want_log_prob else None
+    with torch.cuda.device(dev):
+        rc = lib.inv_sample_actions(_ptr(logits), b, _ptr(seed), _ptr(a64) if a64 is not None else None, _ptr(a8) if a8 is not None else None,
+                                    _ptr(lp) if lp is not None else None, _stream())
+    L.raise_for(rc, lib)
+    return a64, a8, lp
+
+
 class FlatAdam:
     """clip_grad_norm_ + Adam over one flat buffer (torch.optim.Adam defaults of the reference: betas (0.9, 0.999), eps 1e-8,
     no weight decay).  `grad_flat`: an existing flat gradient bucket whose slices already are the parameters' .grad in

@@ -122,9 +122,15 @@ class PPOAgent:
                                         self._t(extra_vectors, torch.float32))
         else:
             logits, values = self.policy(self._planes(grid_tensors), self._t(extra_vectors, torch.float32))
-        dist = torch.distributions.Categorical(logits=logits, validate_args=False)
-        actions = dist.sample()
-        log_probs = dist.log_prob(actions)
+        self.last_actions_u8 = None
+        if self.fused is not None and logits.is_cuda:
+            # one kernel instead of torch.distributions + multinomial (~25 launches); also leaves the uint8 form inv_step reads
+            from .flat_optim import sample_actions
+            actions, self.last_actions_u8, log_probs = sample_actions(logits, want_u8=True)
+        else:
+            dist = torch.distributions.Categorical(logits=logits, validate_args=False)
+            actions = dist.sample()
+            log_probs = dist.log_prob(actions)
         values = values.squeeze(-1)
         if as_numpy:
             return actions.cpu().numpy(), log_probs.cpu().numpy(), values.cpu().numpy()

@@ -82,6 +82,10 @@ class RolloutCollector:
         if self.packed and hasattr(self.opponent, "parameters"):      # an nn.Module opponent wants f32 planes
             grid = unpack_obs(grid, self.batch.H, self.batch.W)
         logits, _ = self.opponent(grid, self.obs_p2[1])
+        from .fused_policy import FusedPolicy
+        if isinstance(self.opponent, FusedPolicy) and logits.is_cuda:
+            from .flat_optim import sample_actions
+            return sample_actions(logits, want_log_prob=False, want_i64=False, want_u8=True)[1]
         return torch.distributions.Categorical(logits=logits, validate_args=False).sample().to(torch.uint8)
 
     def collect(self, steps):
@@ -94,7 +98,8 @@ class RolloutCollector:
                 self.opponent_actions.append(a2)
             # fresh obs buffers per step: the rollout buffer keeps references to them (ppo_agent.py:119)
             out = b._alloc_out((), True, self.selfplay, False, None, self.packed)
-            r = b.step(actions.to(torch.uint8), a2, auto_reset=True, out=out)
+            a1 = getattr(agent, "last_actions_u8", None)
+            r = b.step(a1 if a1 is not None else actions.to(torch.uint8), a2, auto_reset=True, out=out)
             agent.store_batch(grid, extra, actions, log_probs, values, r.reward, r.done)
             self.obs = (r.obs, r.extra)
             if self.selfplay:

@@ -115,3 +115,35 @@ def test_agent_with_fused_update_owns_flat_parameters_and_actor_sees_updates():
     pol2.load_state_dict({k: v.cpu() for k, v in agent.policy.state_dict().items()})
     agent.policy.load_state_dict(pol2.state_dict())                      # in-place copy: the aliasing must survive
     agent.flat_adam._check_aliases()
+
+
+def test_sample_actions_is_categorical_sampling_with_the_loss_kernels_log_probs():
+    """inv_sample_actions: the sampled distribution is softmax(logits) (chi-square over 2 M draws of one row), log_prob is the
+    log-softmax entry of the sampled action (to f32 round-off of torch's, and bit-equal to what inv_ppo_loss computes: ratio 1),
+    torch.manual_seed controls the stream, both action forms agree."""
+    import torch
+    from inversus_reinforcement_learning_amd.flat_optim import ppo_loss, sample_actions
+    torch.manual_seed(3)
+    row = torch.tensor([0.3, -1.2, 2.0, 0.0, -3.0, 1.1, 0.7, -0.4, 0.9, -2.2, 0.1, 1.6, -0.8], device="cuda")
+    n = 1 << 21
+    logits = row.repeat(n, 1)
+    a, a8, lp = sample_actions(logits, want_u8=True)
+    assert a.dtype == torch.int64 and a8.dtype == torch.uint8 and torch.equal(a, a8.long()) and int(a.min()) >= 0 and int(a.max()) <= 12
+    p = torch.softmax(row.double(), 0)
+    counts = torch.bincount(a, minlength=13).double()
+    chi2 = float((((counts - n * p) ** 2) / (n * p)).sum())
+    assert chi2 < 45.0, chi2                                               # 12 degrees of freedom: P(chi2 > 45) ~ 1e-5
+    want_lp = torch.log_softmax(logits[:4096], -1).gather(1, a[:4096, None]).squeeze(1)
+    assert float((lp[:4096] - want_lp).abs().max()) < 1e-6
+    # varied logits: the same log-probs as the loss kernel -> policy term of the loss = -mean(A) exactly (ratio == 1)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    lg = torch.randn(5000, 13, device="cuda", generator=g) * 2
+    torch.manual_seed(11); a1, _, lp1 = sample_actions(lg)
+    torch.manual_seed(11); a2, _, lp2 = sample_actions(lg)
+    torch.manual_seed(12); a3, _, _ = sample_actions(lg)
+    assert torch.equal(a1, a2) and torch.equal(lp1, lp2) and not torch.equal(a1, a3)
+    adv = torch.randn(5000, device="cuda", generator=g)
+    _, means = ppo_loss(lg, torch.zeros(5000, device="cuda"), a1, lp1, adv, torch.zeros(5000, device="cuda"), 0.2, 0.1, 0.02)
+    assert abs(float(means[0]) + float(adv.double().mean())) < 1e-6
+    # every row gets its own uniform: a batch of identical rows does not produce identical actions
+    assert len(torch.unique(a[:64])) > 1

@@ -205,7 +205,8 @@ def test_rollout_forward_uses_the_updates_numerics_when_the_update_is_fused():
         for t in range(T):
             lo_t, v_t = agent.train_fwd(agent.obs_grid_buffer[t], agent.obs_extra_buffer[t])
             lp_t = torch.distributions.Categorical(logits=lo_t.float(), validate_args=False).log_prob(agent.action_buffer[t])
-            assert torch.equal(lp_t, agent.log_prob_buffer[t]) and torch.equal(v_t.float().squeeze(-1), agent.value_buffer[t])
+            # stored log-probs come from inv_sample_actions (the loss kernel's log-softmax expressions), lp_t from torch's
+            assert float((lp_t - agent.log_prob_buffer[t]).abs().max()) < 1e-6 and torch.equal(v_t.float().squeeze(-1), agent.value_buffer[t])
         lo_i, _ = FusedPolicy(pol)(grid, extra)                  # inference epilogue: close, but not the same numbers
         lp_i = torch.distributions.Categorical(logits=lo_i.float(), validate_args=False).log_prob(acts)
         assert 5e-4 < float((lp_i - old_lp).abs().max()) < 0.1
