@@ -233,6 +233,13 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     const float vlast = pix[NW - 1] < P ? 1.0f : 0.0f;
 #endif
     float s = 0.0f, ss = 0.0f;
+#ifndef POL_PK
+#define POL_PK 1
+#endif
+    // POL_PK: the sums run on accumulator PAIRS with v_pk_add_f32 / v_pk_fma_f32 (4 instructions per quad instead of 10; VALU issue,
+    // not LDS or latency, is what the knock-out probes show to be scarce).  Every instantiation sums in the same order.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 s2 = { 0.0f, 0.0f }, ss2 = { 0.0f, 0.0f };
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         const int ch0 = (m0 + mi) * 16 + 4 * kg;
@@ -244,6 +251,14 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
                 x0 += (float)rq[0]; x1 += (float)rq[1]; x2 += (float)rq[2]; x3 += (float)rq[3];
                 acc[mi][i][0] = x0; acc[mi][i][1] = x1; acc[mi][i][2] = x2; acc[mi][i][3] = x3;
             }
+            if (POL_PK && POL_ROWTILES) {
+                const f32x2 pa = { x0, x1 }, pb = { x2, x3 };
+                s2 += pa;
+                s2 += pb;
+                ss2 = __builtin_elementwise_fma(pa, pa, ss2);
+                ss2 = __builtin_elementwise_fma(pb, pb, ss2);
+                continue;
+            }
             // only the wave's LAST tile can hold columns past pixel 149 (150 = 9 x 16 + 6): every other tile is summed
             // unconditionally and the last one through a 0 / 1 factor -- no exec-mask branch per tile (the per-tile `if`
             // compiled to 20 s_and_saveexec / s_cbranch pairs with out-of-line bodies per layer and wave)
@@ -252,6 +267,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             else { s = fmaf(vlast, t1, s); ss = fmaf(vlast, t2, ss); }
         }
     }
+    if (POL_PK && POL_ROWTILES) { s = s2[0] + s2[1]; ss = ss2[0] + ss2[1]; }
     if (!vcol) { s = 0.0f; ss = 0.0f; }                              // row tiles: the dummy column's sums
     s = wave_sum(s);
     ss = wave_sum(ss);
@@ -316,6 +332,32 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
                 if (POL_ROWTILES ? vcol : (i + 1 < NW || pix[i] < P)) {
                     bf16x4 o;
                     const f16x8 q = ln[mi][i];
+#if POL_PK
+                    // pairs: x^ by one v_pk_fma_f32, ReLU AFTER the bf16 rounding as a signed 16-bit maximum with 0 on the packed pair
+                    // (v_pk_max_i16: a negative bf16 is a negative int16; relu(round(x)) == round(relu(x))): 5 instead of 7 per pair
+                    typedef short s16x2 __attribute__((ext_vector_type(2)));
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 rs2 = { rstd, rstd }, sh2 = { shift, shift };
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 a2 = { acc[mi][i][2 * h], acc[mi][i][2 * h + 1] };
+                        f32x2 xh = __builtin_elementwise_fma(a2, rs2, sh2);
+                        if (TN) { xh[0] = (float)(bf16)xh[0]; xh[1] = (float)(bf16)xh[1]; }     // train numerics: see below
+                        // x^ * w + b with the fp16 parameters read in place (v_fma_mix_f32: f32 x f16 + f16, one rounding -- measured equal
+                        // to v_fma_f32 on converted operands, tools/fma_mix_probe.hip); written as asm because hipcc otherwise pairs the two
+                        // fmaf into a v_pk_fma_f32 fed by four v_cvt_f32_f16 (5 instructions instead of 2)
+                        const uint32_t wq = __builtin_bit_cast(u32x4, q)[h], bq = __builtin_bit_cast(u32x4, q)[2 + h];
+                        float y0, y1;
+                        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(y0) : "v"(xh[0]), "v"(wq), "v"(bq));
+                        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(y1) : "v"(xh[1]), "v"(wq), "v"(bq));
+                        uint32_t yp;                                       // both roundings in one instruction (hipcc: two + a v_perm_b32)
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(yp) : "v"(y0), "v"(y1));
+                        const s16x2 z2 = { 0, 0 };
+                        const bf16x2 r = __builtin_bit_cast(bf16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, yp), z2));
+                        o[2 * h] = r[0]; o[2 * h + 1] = r[1];
+                    }
+#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float xh = fmaf(acc[mi][i][e], rstd, shift);
@@ -324,6 +366,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
                         if (TN) xh = (float)(bf16)xh;
                         o[e] = (bf16)fmaxf(fmaf(xh, (float)q[e], (float)q[4 + e]), 0.0f);
                     }
+#endif
                     // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
                     // above, and the residual read of this lane's own elements precedes this write
                     *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
