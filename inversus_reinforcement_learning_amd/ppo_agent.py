@@ -112,9 +112,10 @@ class PPOAgent:
 
     # ------------------------------------------------------------------ act (ppo_agent.py:68-106)
     @torch.no_grad()
-    def act(self, grid_tensors, extra_vectors):
+    def act(self, grid_tensors, extra_vectors, *, with_u8=False):
         """Sample actions.  NumPy in -> NumPy out (reference contract); device tensors in -> device
-        tensors out (actions int64, log_probs f32, values f32)."""
+        tensors out (actions int64, log_probs f32, values f32).  with_u8 (device tensors only): a fourth result, the
+        actions as the uint8 buffer inv_step reads (the sampling kernel writes both forms) or None."""
         as_numpy = not isinstance(grid_tensors, torch.Tensor)
         self.policy.eval()
         if self.fused is not None:                                # reads f32 planes or packed observations directly
@@ -122,11 +123,11 @@ class PPOAgent:
                                         self._t(extra_vectors, torch.float32))
         else:
             logits, values = self.policy(self._planes(grid_tensors), self._t(extra_vectors, torch.float32))
-        self.last_actions_u8 = None
+        actions_u8 = None
         if self.fused is not None and logits.is_cuda:
             # one kernel instead of torch.distributions + multinomial (~25 launches); also leaves the uint8 form inv_step reads
             from .flat_optim import sample_actions
-            actions, self.last_actions_u8, log_probs = sample_actions(logits, want_u8=True)
+            actions, actions_u8, log_probs = sample_actions(logits, want_u8=True)
         else:
             dist = torch.distributions.Categorical(logits=logits, validate_args=False)
             actions = dist.sample()
@@ -134,7 +135,7 @@ class PPOAgent:
         values = values.squeeze(-1)
         if as_numpy:
             return actions.cpu().numpy(), log_probs.cpu().numpy(), values.cpu().numpy()
-        return actions, log_probs, values
+        return (actions, log_probs, values, actions_u8) if with_u8 else (actions, log_probs, values)
 
     # ------------------------------------------------------------------ GAE (ppo_agent.py:127-157)
     def _stacked(self):

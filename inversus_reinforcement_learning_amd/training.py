@@ -92,13 +92,12 @@ class RolloutCollector:
         b, agent = self.batch, self.agent
         for _ in range(steps):
             grid, extra = self.obs
-            actions, log_probs, values = agent.act(grid, extra)
+            actions, log_probs, values, a1 = agent.act(grid, extra, with_u8=True)
             a2 = self._opponent_actions() if self.selfplay else None
             if self.opponent_actions is not None and a2 is not None:
                 self.opponent_actions.append(a2)
             # fresh obs buffers per step: the rollout buffer keeps references to them (ppo_agent.py:119)
             out = b._alloc_out((), True, self.selfplay, False, None, self.packed)
-            a1 = getattr(agent, "last_actions_u8", None)
             r = b.step(a1 if a1 is not None else actions.to(torch.uint8), a2, auto_reset=True, out=out)
             agent.store_batch(grid, extra, actions, log_probs, values, r.reward, r.done)
             self.obs = (r.obs, r.extra)
