@@ -190,7 +190,9 @@ def side_measurements(torch, np, n):
     guard("step selfplay 15x10, PACKED P1+P2 obs (INV_STEP_OBS_BITS)", step_cfg(15, 10, "selfplay", "easy", True, True, bits=True))
 
     def rollout_cfg(T=32):
-        """The persistent multi-step variant: T vector steps in ONE launch (inv_rollout) against T single launches."""
+        """The persistent multi-step variant: T vector steps in ONE launch (inv_rollout) against T single launches.
+        The launch writes T DISTINCT output slots (3.8 GB: an HBM stream); `single launches` here re-write ONE slot (Infinity-Cache
+        resident, like the headline loop) -- the like-for-like single-launch figure is the next entry (distinct buffers)."""
         b = DeviceEnvBatch(n, 15, 10, K, opponent="dummy", difficulty="easy", opp_seed=1)
         b.seed(np.arange(n, dtype=np.int64)); b.reset()
         a1 = torch.stack([b.uniform_actions(7, t) for t in range(T)])
@@ -205,7 +207,7 @@ def side_measurements(torch, np, n):
         us1 = timed(single, 6 * T, warm=T)
         by = algorithmic_bytes_per_env_step() * n
         return {"T": T, "us_per_vector_step_in_one_launch": round(us, 2), "GBps": round(by / us / 1e3, 1),
-                "us_per_vector_step_single_launches": round(us1, 2), "GBps_single_launches": round(by / us1 / 1e3, 1)}
+                "us_per_vector_step_single_launches_one_buffer": round(us1, 2), "GBps_single_launches_one_buffer": round(by / us1 / 1e3, 1)}
     guard("inv_rollout vs_dummy_easy 15x10 (T steps per launch)", rollout_cfg)
 
     def streaming_cfg(T=32):
