@@ -102,3 +102,38 @@ def test_training_loop_over_rccl_with_one_rank():
     env["PYTHONPATH"] = ROOT
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0 and "RCCL_TRAIN_OK 8192" in p.stdout, p.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_fused_training_with_two_ranks_keeps_the_replicas_identical():
+    """The fused update on two ranks (gloo, both ranks on the one GPU): the gradient path that bypasses the autograd engine
+    (FusedTrainPolicy.loss_and_grads) starts the heads' all-reduce explicitly (FlatGradReducer.start_early), reduces the rest after
+    the trunk's backward and steps the flat Adam kernel with 1 / world_size; after three updates both ranks hold the same parameters
+    (training.py additionally checks the digests across ranks while it runs)."""
+    code = ("import os\n"
+            "from inversus_reinforcement_learning_amd import training, parallel\n"
+            "import torch.distributed as dist\n"
+            "r = training.train_selfplay(num_envs=256, total_steps=256*128*3, log_dir=None, seed=5, verbose=False,\n"
+            "                            agent_kwargs=dict(fused_act=True, fused_update=True, batch_size=4096, epochs=1))\n"
+            "assert dist.is_initialized() and dist.get_world_size() == 2\n"
+            "print('FUSED2_OK', os.environ['RANK'], r['steps'], repr(r['param_abs_sum']))\n"
+            "dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    env.update(PYTHONPATH=ROOT, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", INVERSUS_DIST_BACKEND="gloo",
+               INVERSUS_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    lines = []
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "FUSED2_OK" in o, o[-3000:]
+        lines.append([ln for ln in o.splitlines() if ln.startswith("FUSED2_OK")][0].split())
+    assert {ln[1] for ln in lines} == {"0", "1"} and lines[0][2] == lines[1][2]
+    assert lines[0][3] == lines[1][3], lines                       # identical parameter digests on both ranks
