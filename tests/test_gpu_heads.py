@@ -206,3 +206,35 @@ def test_bad_arguments_are_refused():
     lst = L.InvHeadsPackList()
     assert lib.inv_heads_pack(C.byref(lst), 9, None) == L.INV_ERR_BAD_ARG and lib.inv_heads_pack(C.byref(lst), 1, None) == L.INV_ERR_BAD_ARG
     assert lib.inv_heads_pack(C.byref(lst), 0, None) == L.INV_OK
+
+
+def test_other_head_sizes_keep_the_torch_tail_and_the_autograd_update():
+    """hidden_dim != 256 has no heads kernel: FusedPolicy / FusedTrainPolicy keep their torch tails (still on the GPU, still the
+    fused trunk) and PPOAgent's fused update goes through autograd instead of loss_and_grads."""
+    import torch
+    from inversus_reinforcement_learning_amd import heads as HD
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    torch.manual_seed(0)
+    pol = InversusCNNPolicy(12, 10, 15, 4, hidden_dim=128).cuda()
+    assert not HD.supported(pol)
+    n, T = 128, 4
+    b = DeviceEnvBatch(n, opponent="dummy", difficulty="hard", opp_seed=1)
+    b.seed(np.arange(n, dtype=np.int64)); b.reset()
+    g, x = b.render(0)
+    f = FusedPolicy(pol)
+    assert f.heads is None
+    with torch.no_grad():
+        lo, v = f(g, x)
+        lm, vm = pol(g, x)
+    assert float((lo - lm).abs().max()) < 0.05 and float((v - vm).abs().max()) < 0.05
+    agent = PPOAgent(pol, fused_act=True, fused_update=True, batch_size=n * T, epochs=1)
+    assert not agent.direct_grads
+    before = float(sum(p.detach().double().abs().sum() for p in pol.parameters()))
+    RolloutCollector(b, agent).collect(T)
+    stats = agent.update()
+    after = float(sum(p.detach().double().abs().sum() for p in pol.parameters()))
+    assert np.isfinite(stats["policy_loss"]) and np.isfinite(stats["entropy"]) and after != before
