@@ -253,6 +253,7 @@ def side_measurements(torch, np, n):
         res = {"fused_trunk_ms": round(timed(lambda: fused.features(g), 40, warm=5) / 1e3, 3),
                "fused_forward_ms": round(timed(lambda: fused(g, x), 40, warm=5) / 1e3, 3)}
         res["fused_trunk_TFLOPs"] = round(72.9e6 * n / (res["fused_trunk_ms"] * 1e-3) / 1e12, 1)
+        res["fused_trunk_frac_of_2500_TFLOPs_dense_bf16_peak"] = round(res["fused_trunk_TFLOPs"] / 2500.0, 3)
         gbits = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, 57), dtype=torch.int32, device="cuda") & \
             torch.randint(-2 ** 31, 2 ** 31 - 1, (n, 57), dtype=torch.int32, device="cuda")        # ~25 % ones
         res["fused_trunk_packed_obs_ms"] = round(timed(lambda: fused.features(gbits), 40, warm=5) / 1e3, 3)
