@@ -119,6 +119,34 @@ def _split_k(B):
     return 1
 
 
+class _SmallGrads:
+    """The small gradients inv_heads_bwd ADDS into: one zeroed f32 buffer with named slices
+    [db1 512 | dwe 512 x 4 | db2 128, 128 | dw3 13 x 128, 1 x 128 | db3 13, 1]."""
+    SIZES = (("db1", 2 * HID), ("dwe", 2 * HID * 4), ("db2_0", MID), ("db2_1", MID), ("dw3_0", NACT * MID), ("dw3_1", MID),
+             ("db3_0", NACT), ("db3_1", 1))
+
+    def __init__(self, device):
+        self.off, n = {}, 0
+        for name, size in self.SIZES:
+            self.off[name] = (n, size)
+            n += size
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+
+    def view(self, name):
+        o, n = self.off[name]
+        return self.buf[o:o + n]
+
+    def ptr(self, name, elem=0):
+        return self.buf.data_ptr() + 4 * (self.off[name][0] + elem)
+
+    def struct(self):
+        gr = L.InvHeadsGrads()
+        gr.db1, gr.dwe = self.ptr("db1"), self.ptr("dwe")
+        for i in range(2):
+            gr.db2[i], gr.dw3[i], gr.db3[i] = self.ptr(f"db2_{i}"), self.ptr(f"dw3_{i}"), self.ptr(f"db3_{i}")
+        return gr
+
+
 class _HeadsTrainFn(torch.autograd.Function):
     """(features bf16, extra, 6 actor tensors, 6 critic tensors) -> (logits, value); gradients for everything but `extra`."""
 
@@ -139,15 +167,8 @@ class _HeadsTrainFn(torch.autograd.Function):
         ops, P, B, dev = ctx.ops, ctx.pixels, feat.shape[0], feat.device
         dlogits = dlogits.float().contiguous() if dlogits is not None else torch.zeros((B, NACT), dtype=torch.float32, device=dev)
         dvalue = dvalue.float().contiguous() if dvalue is not None else torch.zeros((B, 1), dtype=torch.float32, device=dev)
-        # small gradients: one zeroed f32 buffer [db1 512 | dwe 2048 | db2 2 x 128 | dw3 13 x 128 + 128 | db3 13 + 1 (+ pad)]
-        small = torch.zeros(512 + 2048 + 256 + 14 * 128 + 16, dtype=torch.float32, device=dev)
-        o = [0, 512, 2560, 2688, 2816, 2816 + 13 * 128, 2816 + 14 * 128, 2816 + 14 * 128 + 13]
-        gr = L.InvHeadsGrads()
-        base, sz = small.data_ptr(), 4
-        gr.db1, gr.dwe = base, base + o[1] * sz
-        gr.db2[0], gr.db2[1] = base + o[2] * sz, base + o[3] * sz
-        gr.dw3[0], gr.dw3[1] = base + o[4] * sz, base + o[5] * sz
-        gr.db3[0], gr.db3[1] = base + o[6] * sz, base + o[7] * sz
+        small = _SmallGrads(dev)
+        gr = small.struct()
         dpre = torch.empty((B, 2 * HID), dtype=torch.bfloat16, device=dev)
         dpre_t = torch.empty((2 * HID, B), dtype=torch.bfloat16, device=dev) if B % 8 == 0 else None
         da2 = torch.empty((B, 2 * MID), dtype=torch.bfloat16, device=dev)
@@ -168,19 +189,17 @@ class _HeadsTrainFn(torch.autograd.Function):
             for i in range(2):
                 dst = getattr(ctx, "fc1_grad_out", None)                              # direct path: the parameter's .grad itself
                 g = dst[i] if dst is not None else torch.empty((HID, 128 * P + 4), dtype=torch.float32, device=dev)
-                L.raise_for(lib.inv_heads_unpack_fc1_grad(_ptr(dwf[HID * i]), C.c_void_p(base + (o[1] + HID * 4 * i) * sz), HID, P, _ptr(g), _stream()), lib)
+                L.raise_for(lib.inv_heads_unpack_fc1_grad(_ptr(dwf[HID * i]), C.c_void_p(small.ptr("dwe", HID * 4 * i)), HID, P, _ptr(g), _stream()), lib)
                 gw1.append(g)
         # dW2 of both heads: split-K batched product [G][256 x B/G] x [G][B/G x 512], its two diagonal blocks are the heads'
         G = _split_k(B)
         part = torch.bmm(da2.view(G, B // G, 2 * MID).transpose(1, 2), h.view(G, B // G, 2 * HID))       # bf16 [G, 256, 512]
         dw2 = part.float().sum(0)
         gw2 = [dw2[:MID, :HID].contiguous(), dw2[MID:, HID:].contiguous()]
-        db1, db2 = small[:512], small[o[2]:o[4]]
         out = [dfeat, None]
-        for i in range(2):
-            n3 = NACT if i == 0 else 1
-            out += [gw1[i], db1[HID * i:HID * (i + 1)], gw2[i], db2[MID * i:MID * (i + 1)], small[o[4 + i]:o[4 + i] + n3 * MID].view(n3, MID),
-                    small[o[6 + i]:o[6 + i] + n3]]
+        for i in range(2):                                                             # order of head_tensors(): W1, b1, W2, b2, W3, b3
+            out += [gw1[i], small.view("db1")[HID * i:HID * (i + 1)], gw2[i], small.view(f"db2_{i}"),
+                    small.view(f"dw3_{i}").view(-1, MID), small.view(f"db3_{i}")]
         return tuple(out)
 
 
