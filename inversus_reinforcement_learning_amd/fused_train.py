@@ -16,6 +16,7 @@ Numerics: bf16 operands with f32 accumulation, like `PPOAgent(update_autocast=to
 the f32 module to ~1e-2 relative (tests/test_gpu_fused_train.py), not bit for bit.  Only the 12 x 10 x 15 observation.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn.functional as F
@@ -73,6 +74,17 @@ def _wgrad(layer, x, dz):
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
     L.raise_for(rc, lib)
     return dw[:, :, :cin].reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous(), db
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One extra stream per device for work that can run beside the main stream's kernels."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
 
 
 class _TrunkTrainFn(torch.autograd.Function):
@@ -146,20 +158,34 @@ class _TrunkTrainFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = lib.inv_policy_obs_to_x0(_ptr(obs), 1 if ctx.bits else 0, _ptr(x0), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.raise_for(rc, lib)
+        # The LayerNorm reductions (HBM-bound: dy and x^ once, 3.4 GB) run on a side stream beside the weight-gradient kernels
+        # (MFMA-bound, 3 GB of x / dz): both only read what the backward kernel wrote.  The main stream waits for the side
+        # stream before returning, so every tensor used there outlives its use.  INVERSUS_PG_STREAM=0: one stream.
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if os.environ.get("INVERSUS_PG_STREAM", "1") != "0" else main
+        if side is not main:
+            side.wait_stream(main)
+        ln_grads = []
+        with torch.cuda.stream(side):
+            for i in range(4):
+                c = _COUT[i]
+                slices = max(1, min(n, _RED_SLICES))
+                part = torch.empty((slices, 2, 150, c), dtype=torch.float32, device=dev)   # per-slice sums of dy*x^, dy
+                with torch.cuda.device(dev):
+                    rc = lib.inv_policy_param_grads(_ptr(dy[i]), _ptr(xhat[i]), _ptr(part), slices, 150 * c, n,
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                L.raise_for(rc, lib)
+                red = part.sum(dim=0)
+                if side is not main:
+                    red.record_stream(main)                                              # consumed on the main stream after the join
+                ln_grads.append((red[0].t().reshape(c, 10, 15), red[1].t().reshape(c, 10, 15)))
         out = [None]
         for i in range(4):
-            c = _COUT[i]
             x_in = x0 if i == 0 else act[i - 1]
             dw, db = _wgrad(i, x_in, dz[i])
-            slices = max(1, min(n, _RED_SLICES))
-            part = torch.empty((slices, 2, 150, c), dtype=torch.float32, device=dev)       # per-slice sums of dy*x^, dy
-            with torch.cuda.device(dev):
-                rc = lib.inv_policy_param_grads(_ptr(dy[i]), _ptr(xhat[i]), _ptr(part), slices, 150 * c, n,
-                                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            L.raise_for(rc, lib)
-            red = part.sum(dim=0)
-            dg, de = red[0].t().reshape(c, 10, 15), red[1].t().reshape(c, 10, 15)
-            out += [dw, db, dg, de]
+            out += [dw, db, ln_grads[i][0], ln_grads[i][1]]
+        if side is not main:
+            main.wait_stream(side)
         return tuple(out)
 
 
