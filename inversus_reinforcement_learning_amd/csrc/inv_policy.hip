@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/inversus_hip.h"
 #include "inv_internal.h"
@@ -1425,6 +1426,11 @@ extern "C" int inv_policy_debug_stamps(unsigned long long *out16_host, int reset
 static int trunk_grid(int N)
 {
     const int cus = inv_cu_count();                  // of the current device (cached per device)
+#ifdef POL_GRID_PROBE
+    const char *e = getenv("POL_BLOCKS_X2");         // probe builds: resident workgroups per 2 CUs (4 = the shipped two per CU)
+    const int per2 = e ? atoi(e) : 4;
+    return N < per2 * cus / 2 ? N : per2 * cus / 2;
+#endif
     return N < 2 * cus ? N : 2 * cus;               // two resident 256-thread workgroups per CU (55 KB of LDS each), persistent over samples
 }
 
