@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define INV_ABI_VERSION 4
+#define INV_ABI_VERSION 5
 
 typedef enum {
     INV_OK = 0,
@@ -135,6 +135,14 @@ int  inv_get_config(const inv_handle *h, inv_config *cfg);
  *   ROW4  as AUTO, but an error where the four-env kernel does not exist */
 enum { INV_STEP_KERNEL_AUTO = 0, INV_STEP_KERNEL_WAVE = 1, INV_STEP_KERNEL_ROW4 = 2 };
 int  inv_set_step_kernel(inv_handle *h, int32_t kind);
+/* Cache policy of the f32 observation stores (inv_step / inv_rollout / inv_render_obs).  Results are identical; speed only.
+ *   AUTO   write-through (`sc1`) stores for launches whose every observation store instruction covers whole 128-B lines --
+ *          the observation pointers are 128-B aligned and either the four-env kernel writes a wave's four 15x10 regions as one
+ *          28 800-B stream (num_envs a multiple of 4) or one region is a multiple of 128 B (W*H a multiple of 8, e.g. 32x32) --
+ *          plain stores otherwise: a partially written line costs a masked write at memory when it is written through
+ *   PLAIN  never write through (the round-1/2 behaviour; A/B runs) */
+enum { INV_OBS_STORE_AUTO = 0, INV_OBS_STORE_PLAIN = 1 };
+int  inv_set_obs_store_policy(inv_handle *h, int32_t policy);
 /* bytes of one env's obs / words per grid, for sizing caller buffers */
 int64_t inv_obs_floats_per_env(const inv_handle *h);   /* 12*H*W */
 int32_t inv_grid_words(const inv_handle *h);           /* GW */

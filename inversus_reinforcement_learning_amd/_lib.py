@@ -20,6 +20,7 @@ INV_STEP_AUTO_RESET, INV_STEP_OBS_BITS, INV_STEP_DEFAULT = 16, 32, 15
 INV_INFO_LANDED_HIT, INV_INFO_GOT_HIT, INV_INFO_WIN, INV_INFO_LOSE = 1, 2, 4, 8
 INV_GAE_REFERENCE_FLAT, INV_GAE_PER_ENV = 0, 1
 INV_STEP_KERNEL_AUTO, INV_STEP_KERNEL_WAVE, INV_STEP_KERNEL_ROW4 = 0, 1, 2
+INV_OBS_STORE_AUTO, INV_OBS_STORE_PLAIN = 0, 1
 
 
 class InvConfig(C.Structure):
@@ -90,6 +91,7 @@ SIGNATURES = {
     "inv_destroy": (C.c_int, [_V]),
     "inv_get_config": (C.c_int, [_V, P(InvConfig)]),
     "inv_set_step_kernel": (C.c_int, [_V, C.c_int32]),
+    "inv_set_obs_store_policy": (C.c_int, [_V, C.c_int32]),
     "inv_obs_floats_per_env": (C.c_int64, [_V]),
     "inv_grid_words": (C.c_int32, [_V]),
     "inv_obs_words_per_env": (C.c_int32, [_V]),

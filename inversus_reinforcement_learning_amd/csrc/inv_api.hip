@@ -32,8 +32,20 @@ __device__ __forceinline__ unsigned long long step_stamp_now()
     return t;
 }
 #define SSTAMP(slot) do { const unsigned long long n_ = step_stamp_now(); st_acc[slot] += n_ - st_prev; st_prev = n_; } while (0)
+// k_step4: ABSOLUTE times of the chip-wide 100 MHz clock, one record per wave (slot = wave index), so that the waves' phases can
+// be laid on one time axis (tools/step4_timeline.py)
+__device__ __forceinline__ unsigned long long wall_stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define WSTAMP(slot) do { wst[slot] = wall_stamp_now(); } while (0)
 #else
 #define SSTAMP(slot) do { } while (0)
+#define WSTAMP(slot) do { } while (0)
 #endif
 
 // LDS slice of a wave: [nibble table 64][grid GW][bullet slots K][scratch >= 624]
@@ -175,8 +187,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
         }
         SSTAMP(4);                                  // reset
 
-        if (o.obs) render_obs(d, g, L.scr, tab, lane, 0, e, o.obs + idx * obs_stride, o.extra ? o.extra + idx * 4 : nullptr, obits);
-        if (o.obs_p2) render_obs(d, g, L.scr, tab, lane, 1, e, o.obs_p2 + idx * obs_stride, o.extra_p2 ? o.extra_p2 + idx * 4 : nullptr, obits);
+        if (o.obs) render_obs(d, g, L.scr, tab, lane, 0, e, o.obs + idx * obs_stride, o.extra ? o.extra + idx * 4 : nullptr, obits, a.obs_wt != 0);
+        if (o.obs_p2) render_obs(d, g, L.scr, tab, lane, 1, e, o.obs_p2 + idx * obs_stride, o.extra_p2 ? o.extra_p2 + idx * 4 : nullptr, obits, a.obs_wt != 0);
     }
 
     SSTAMP(5);                                      // observation render(s)
@@ -214,6 +226,10 @@ __global__ __launch_bounds__(kWave * WPB) void k_step4(StepArgs a)
     const int N = a.d.N;
     const int env0 = (xcd_block((int)blockIdx.x, (int)gridDim.x) * WPB + wv) * kRows;   // first env of this wave (uniform)
     if (env0 >= N) return;
+#ifdef INV_STEP_STAMPS
+    unsigned long long wst[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+    WSTAMP(0);                                                              // wave started
     const int env = env0 + r;
     const bool valid = env < N;
     const int envc = valid ? env : 0;
@@ -230,6 +246,7 @@ __global__ __launch_bounds__(kWave * WPB) void k_step4(StepArgs a)
 
     Row e;
     load_rows<D>(a.s, env, l, valid, rowp, e);
+    WSTAMP(1);                                                              // state in registers / LDS
     uint32_t err = 0u;
     const bool obits = (a.flags & INV_STEP_OBS_BITS) != 0u;
     const size_t obs_stride = obits ? (size_t)D::OW : (size_t)12 * D::WH;
@@ -304,6 +321,7 @@ __global__ __launch_bounds__(kWave * WPB) void k_step4(StepArgs a)
             if (a.o.episode_return) a.o.episode_return[idx] = e.ep_ret;
         }
 
+        WSTAMP(2);                                                          // tick + reward + scalar outputs issued
         // training.py:148-151: rows whose episode ended are reset one after the other by the whole wave (MT19937 of inv_device.h)
         uint64_t need = __ballot(auto_reset && done && valid && l == 0);
         while (need) {
@@ -323,12 +341,22 @@ __global__ __launch_bounds__(kWave * WPB) void k_step4(StepArgs a)
             }
         }
 
+        WSTAMP(3);                                                          // resets done
         const int nvalid = min(kRows, N - env0);                            // rows of this wave that are envs
         const size_t idxr = (size_t)t * N + env;                            // this row's slot (past the end for rows >= nvalid: never written)
-        if (a.o.obs) render4<D>(g, reg, tab, lane, 0, e, valid, nvalid, LL::row_words, a.o.obs + idxr * obs_stride, a.o.extra ? a.o.extra + idxr * 4 : nullptr, obits);
-        if (a.o.obs_p2) render4<D>(g, reg, tab, lane, 1, e, valid, nvalid, LL::row_words, a.o.obs_p2 + idxr * obs_stride, a.o.extra_p2 ? a.o.extra_p2 + idxr * 4 : nullptr, obits);
+        // the observation regions of a wave's envs are adjacent: render4 gets the (wave-uniform) address of the first one
+        if (a.o.obs) render4<D>(g, reg, tab, lane, 0, e, valid, nvalid, LL::row_words, a.o.obs + idx0 * obs_stride, a.o.extra ? a.o.extra + idxr * 4 : nullptr, obits, a.obs_wt != 0);
+        if (a.o.obs_p2) render4<D>(g, reg, tab, lane, 1, e, valid, nvalid, LL::row_words, a.o.obs_p2 + idx0 * obs_stride, a.o.extra_p2 ? a.o.extra_p2 + idxr * 4 : nullptr, obits, a.obs_wt != 0);
     }
+    WSTAMP(4);                                                              // observation stores issued
     store_rows<D>(a.s, env, l, valid, rowp, e);
+#ifdef INV_STEP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WSTAMP(5);                                                              // every store of this wave acknowledged
+    if (lane == 0 && env0 / kRows < kStampEnvs) {
+        for (int q = 0; q < 8; ++q) g_step_stamps[(env0 / kRows) * 8 + q] = wst[q];
+    }
+#endif
     // rows past N step a copy of env 0 on whatever bytes follow the action buffer: their state is never stored and their
     // errors are not errors
     if (__ballot(err != 0u && valid) != 0ull) {
@@ -353,7 +381,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_reset(Dims dd, State
 }
 
 template <class D>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims dd, State s, int player, float *obs, float *extra, int as_bits)
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims dd, State s, int player, float *obs, float *extra, int as_bits, int obs_wt)
 {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & (kWave - 1), wv = rfl((int)(threadIdx.x >> 6));
@@ -365,7 +393,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims dd, Stat
     Env e;
     load_env(d, s, env, lane, L.g, e);
     render_obs(d, L.g, L.scr, reinterpret_cast<const float4 *>(L.tabw), lane, player, e,
-               obs + (size_t)env * (as_bits ? (size_t)d.OW : (size_t)12 * d.WH), extra ? extra + (size_t)env * 4 : nullptr, as_bits != 0);
+               obs + (size_t)env * (as_bits ? (size_t)d.OW : (size_t)12 * d.WH), extra ? extra + (size_t)env * 4 : nullptr, as_bits != 0, obs_wt != 0);
 }
 
 // Packed observation bitstring -> f32 planes: float4 q of env i = nibble (q & 7) of word q >> 3 (the same
@@ -522,6 +550,7 @@ struct inv_handle {
     uint32_t *keys_host; // pinned, same layout
     int lds_bytes;
     int step4_mode;      // full unmasked steps: 0 wave-per-env kernel, 1 auto (see launch_step), 2 four-envs-per-wave kernel
+    int obs_store_plain; // inv_set_obs_store_policy(INV_OBS_STORE_PLAIN): never write the f32 observations through
 };
 
 static thread_local char g_err[512] = "";
@@ -659,6 +688,15 @@ int inv_set_step_kernel(inv_handle *h, int32_t kind)
     return INV_OK;
 }
 
+int inv_set_obs_store_policy(inv_handle *h, int32_t policy)
+{
+    if (!h) return fail(INV_ERR_BAD_ARG, "inv_set_obs_store_policy: NULL handle");
+    if (policy != INV_OBS_STORE_AUTO && policy != INV_OBS_STORE_PLAIN)
+        return fail(INV_ERR_BAD_ARG, "inv_set_obs_store_policy: unknown policy %d", (int)policy);
+    h->obs_store_plain = policy == INV_OBS_STORE_PLAIN;
+    return INV_OK;
+}
+
 int inv_get_config(const inv_handle *h, inv_config *cfg)
 {
     if (!h || !cfg) return fail(INV_ERR_BAD_ARG, "inv_get_config: NULL argument");
@@ -702,6 +740,17 @@ int inv_reset(inv_handle *h, const uint8_t *mask, void *stream)
     return INV_OK;
 }
 
+// Write-through observation stores only where every store instruction covers whole 128-B lines (inv_device.h::store_f4):
+// `group4` = the launch runs k_step4 on the 15x10 board, which writes a wave's four 7 200-B regions as one 28 800-B stream.
+static inline bool aligned128(const void *p) { return ((uintptr_t)p & 127u) == 0u; }
+static int obs_write_through(const inv_handle *h, bool group4, const float *obs, const float *obs_p2)
+{
+    if (h->obs_store_plain || (!obs && !obs_p2)) return 0;
+    if ((obs && !aligned128(obs)) || (obs_p2 && !aligned128(obs_p2))) return 0;
+    if (group4) return h->d.N % inv4::kRows == 0;
+    return h->d.WH % 8 == 0;                         // one region = 48 * WH bytes
+}
+
 static int launch_step(inv_handle *h, int T, const uint8_t *mask, const uint8_t *a1, const uint8_t *a2, uint32_t flags, const inv_step_out *out, void *stream)
 {
     if (!h || !a1) return fail(INV_ERR_BAD_ARG, "inv_step: NULL handle or a1");
@@ -725,8 +774,10 @@ static int launch_step(inv_handle *h, int T, const uint8_t *mask, const uint8_t 
     // the 32x32 board with packed observations; 32x32 with f32 planes (0.8 GB of stores per step, store-bound either way)
     // stays on the wave-per-env kernel, which was 4 % faster there.
     const bool bits = (flags & INV_STEP_OBS_BITS) != 0u;
+    a.obs_wt = bits ? 0 : obs_write_through(h, false, a.o.obs, a.o.obs_p2);
     if (h->step4_mode && full && h->d.W == 15 && h->d.H == 10) {
         using DT = StaticDims<15, 10, 16>;
+        a.obs_wt = bits ? 0 : obs_write_through(h, true, a.o.obs, a.o.obs_p2);
         constexpr int WPB = 4, lds = inv4::Lds4<DT>::wave_words * 4 * WPB;
         const int blocks = (h->d.N + inv4::kRows * WPB - 1) / (inv4::kRows * WPB);
         if (T == 1) hipLaunchKernelGGL((k_step4<DT, true, WPB>), dim3(blocks), dim3(kWave * WPB), lds, (hipStream_t)stream, a);
@@ -776,7 +827,7 @@ static int launch_render(inv_handle *h, int32_t player, float *obs, float *extra
     if (!h || !obs) return fail(INV_ERR_BAD_ARG, "inv_render_obs: NULL argument");
     if (player != 0 && player != 1) return fail(INV_ERR_BAD_ARG, "Invalid player ID: %d", player);   // core.py:198
     INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL(k_render<DT>, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes,
-                                               (hipStream_t)stream, h->d, h->s, player, obs, extra, as_bits));
+                                               (hipStream_t)stream, h->d, h->s, player, obs, extra, as_bits, as_bits ? 0 : obs_write_through(h, false, obs, nullptr)));
     HIP_TRY(hipGetLastError());
     return INV_OK;
 }

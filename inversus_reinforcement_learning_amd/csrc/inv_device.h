@@ -89,6 +89,7 @@ struct StepArgs {
     uint32_t opp_seed;
     uint32_t env_offset;
     int T;               // vector steps in this launch (inv_rollout); 1 for inv_step
+    int obs_wt;          // f32 observation stores write through (every store instruction of the launch covers whole 128-B lines)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each with its own L2.  Consecutive envs
@@ -535,6 +536,22 @@ __device__ inline int dummy_action(const D &d, const uint32_t *g, int lane, cons
     return 0;                                                              // :170
 }
 
+// Observation f32 stores go through the buffer-store builtin, whose cache-policy bits are an immediate: AUX = 0 plain (the line
+// stays dirty in the XCD's L2 until it is evicted or the kernel ends), AUX = 16 `sc1` = write-through.  Write-through is what a
+// 100+ MB stream wants -- nothing is left for the end-of-kernel L2 write-back (15x10, same box: 20.2 -> 18.5 us per vector step
+// on a cache-resident buffer, 27.2 -> 25.1 us streaming into 32 buffers) -- but ONLY for stores that cover whole 128-B lines: a
+// partially written line goes to memory as a masked write (a pure-store kernel over 7 200-B regions, 2 partial lines in 57:
+// 20.9 us plain, 31.0 us write-through; tools/wstream2.hip, profiles/r03_store_policy.md).  So the kernels take it as a launch
+// parameter (StepArgs::obs_wt) that the host sets when every store instruction of the launch is line-aligned.
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+
+template <int AUX>
+__device__ __forceinline__ void store_f4(float4 v, __amdgpu_buffer_rsrc_t rs, int byte_off)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, v), rs, byte_off, 0, AUX);
+}
+constexpr int kStorePlain = 0, kStoreWriteThrough = 16;
+
 // ------------------------------------------------------------------ observation (env_wrappers.py:173-245)
 // f32(k / 6) for k = 0..6, folded at compile time (IEEE f64 divide, then one rounding to f32) -- the values
 // `player.ammo / MAX_AMMO` takes in env_wrappers.py:239-240.  Other ammo values exist only via inv_set_state.
@@ -565,7 +582,7 @@ __device__ __forceinline__ void init_nibble_table(float *tab, int lane)
 // consecutive 16 B, 1 KiB per wave store instruction.
 template <class D>
 __device__ inline void render_obs(const D &d, const uint32_t *g, uint32_t *ob, const float4 *tab, int lane, int pid,
-                                  const Env &e, float *__restrict__ obs_env, float *__restrict__ extra_env, bool as_bits = false)
+                                  const Env &e, float *__restrict__ obs_env, float *__restrict__ extra_env, bool as_bits = false, bool wt = false)
 {
     const int WH = d.WH;
     const uint32_t lastmask = (WH & 31) ? ((1u << (WH & 31)) - 1u) : 0xffffffffu;
@@ -597,11 +614,15 @@ __device__ inline void render_obs(const D &d, const uint32_t *g, uint32_t *ob, c
         uint32_t *bdst = reinterpret_cast<uint32_t *>(obs_env);
         for (int w = lane; w < d.OW; w += kWave) bdst[w] = ob[w];
     } else {
-        float4 *dst = reinterpret_cast<float4 *>(obs_env);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(obs_env, 0, d.F4 * 16, 0x00020000);   // obs_env is wave-uniform
         const uint32_t sh = (uint32_t)(lane & 7) * 4u;
+        if (wt) {
 #pragma unroll 4
-        // (default-policy stores: non-temporal stores measured 30.7 us vs 20.0 us for this stream)
-        for (int j = lane; j < d.F4; j += kWave) dst[j] = tab[(ob[j >> 3] >> sh) & 15u];
+            for (int j = lane; j < d.F4; j += kWave) store_f4<kStoreWriteThrough>(tab[(ob[j >> 3] >> sh) & 15u], rs, j * 16);
+        } else {
+#pragma unroll 4
+            for (int j = lane; j < d.F4; j += kWave) store_f4<kStorePlain>(tab[(ob[j >> 3] >> sh) & 15u], rs, j * 16);
+        }
     }
     if (extra_env && lane < 4) {                                            // :238-243: f32(ammo / 6) computed in f64
         const Player &q = (lane & 1) ? en : me;

@@ -16,6 +16,8 @@
 // (the state-poking test surface) stay on k_step.  tests/ run every parity test through both kernels.
 #pragma once
 
+#include <utility>
+
 #include "inv_device.h"
 
 namespace inv4 {
@@ -257,9 +259,50 @@ __device__ __forceinline__ int dummy_action4(const uint32_t *g, int lane, int l,
 }
 
 // ------------------------------------------------------------------ observation (env_wrappers.py:173-245)
+// One store instruction (64 lanes x 16 B) of a wave's GROUP stream: the kRows regions of a wave's envs are adjacent in the
+// observation buffer (F4 float4s each), so the wave writes them as one run of kRows * F4 float4s -- at 15x10 that is
+// 28 800 B = 225 whole 128-B lines starting on a line (4 regions of 7 200 B; one region alone starts and ends inside a line),
+// 28 full store instructions + one of 8 lanes instead of 4 x (7 + a 2-lane tail).  float4 j of the group = float4
+// q = j - rr * F4 of row rr = nibble (q & 7) of word q >> 3 of that row's bitstring.  I is a compile-time instruction index,
+// so rr, the LDS word offset and the store offset fold into immediates; wq / sh hold the per-lane parts of (q >> 3) and
+// 4 * (q & 7), which depend on rr only through (rr * F4) mod 8.
+template <class D, int AUX, int I>
+__device__ __forceinline__ void group_store(__amdgpu_buffer_rsrc_t rs, const uint32_t *ob0, const float4 *tab, int lane, int row_words,
+                                            const int (&wq)[kRows], const uint32_t (&sh)[kRows])
+{
+    constexpr int F4 = D::F4, total = kRows * F4, lo = 64 * I, hi = 64 * I + 63;
+    if constexpr (lo < total) {
+        constexpr int hic = hi < total ? hi : total - 1;
+        constexpr int ra = lo / F4, rb = hic / F4;                           // F4 >= 64: a 64-lane window meets at most one boundary
+        // q = lane + c with c = lo - rr * F4 = 8 * cd + cm (0 <= cm < 8): q >> 3 = ((lane + cm) >> 3) + cd
+        constexpr int ca = lo - ra * F4, cda = (ca - (((ca % 8) + 8) % 8)) / 8;
+        constexpr int cb = lo - rb * F4, cdb = (cb - (((cb % 8) + 8) % 8)) / 8;
+        const int j = lane + lo;
+        uint32_t word, shift;
+        if constexpr (ra == rb) {
+            word = ob0[ra * row_words + cda + wq[ra]];
+            shift = sh[ra];
+        } else {
+            const bool up = j >= rb * F4;
+            word = ob0[up ? rb * row_words + cdb + wq[rb] : ra * row_words + cda + wq[ra]];
+            shift = up ? sh[rb] : sh[ra];
+        }
+        const float4 v = tab[(word >> shift) & 15u];
+        if (hi < total || j < total) store_f4<AUX>(v, rs, j * 16);
+    }
+}
+
+template <class D, int AUX, int... Is>
+__device__ __forceinline__ void group_store_all(__amdgpu_buffer_rsrc_t rs, const uint32_t *ob0, const float4 *tab, int lane, int row_words,
+                                                const int (&wq)[kRows], const uint32_t (&sh)[kRows], std::integer_sequence<int, Is...>)
+{
+    (group_store<D, AUX, Is>(rs, ob0, tab, lane, row_words, wq, sh), ...);
+}
+
+// obs_wave: the region of the wave's FIRST env (wave-uniform pointer); row r's region follows r * obs_stride elements later.
 template <class D>
 __device__ __forceinline__ void render4(const uint32_t *g, uint32_t *ob, const float4 *tab, int lane, int pid, const Row &e, bool valid,
-                                        int nvalid, int row_words, float *__restrict__ obs_env, float *__restrict__ extra_env, bool as_bits)
+                                        int nvalid, int row_words, float *__restrict__ obs_wave, float *__restrict__ extra_env, bool as_bits, bool wt)
 {
     const int l = lane & (kRowLanes - 1), r = lane >> 4;
     constexpr int WH = D::WH;
@@ -283,25 +326,44 @@ __device__ __forceinline__ void render4(const uint32_t *g, uint32_t *ob, const f
         }
     }
     wave_sync();
+    const uint32_t *ob0 = ob - (ptrdiff_t)r * row_words;                    // row 0's bitstring (this lane's region is row r's)
     if (as_bits) {
         if (valid) {
-            uint32_t *bdst = reinterpret_cast<uint32_t *>(obs_env);
+            uint32_t *bdst = reinterpret_cast<uint32_t *>(obs_wave) + (size_t)r * D::OW;
             for (int w = l; w < D::OW; w += kRowLanes) bdst[w] = ob[w];
         }
+    } else if ((D::F4 % kWave) != 0 && nvalid == kRows) {
+        // f32 planes, regions that are not whole store instructions (15x10: 450 float4s): one group stream, see group_store
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(obs_wave, 0, kRows * D::F4 * 16, 0x00020000);
+        int wq[kRows];
+        uint32_t sh[kRows];
+#pragma unroll
+        for (int rr = 0; rr < kRows; ++rr) {
+            const int cm = (8 - (rr * D::F4) % 8) % 8;                       // (-rr * F4) mod 8
+            wq[rr] = (lane + cm) >> 3;
+            sh[rr] = (uint32_t)((lane + cm) & 7) * 4u;
+        }
+        constexpr auto seq = std::make_integer_sequence<int, (kRows * D::F4 + kWave - 1) / kWave>{};
+        if (wt) group_store_all<D, kStoreWriteThrough>(rs, ob0, tab, lane, row_words, wq, sh, seq);
+        else group_store_all<D, kStorePlain>(rs, ob0, tab, lane, row_words, wq, sh, seq);
     } else {
         // f32 planes: the WHOLE wave expands one row's bitstring after the other, so that every store instruction writes
         // 1 KiB of consecutive addresses (64 lanes x 16 B) like the wave-per-env kernel -- with each row expanding its own
         // env (4 x 256-B pieces per instruction) the same stream ran 10 % slower once it no longer fit the Infinity Cache.
         // float4 j of an env = nibble (j & 7) of word j >> 3; j = lane (mod 64) keeps the nibble position per lane.
-        const uint32_t sh = (uint32_t)(lane & 7) * 4u;
-        const ptrdiff_t obs_row_stride = (ptrdiff_t)12 * WH;               // floats between consecutive envs
+        const uint32_t shl = (uint32_t)(lane & 7) * 4u;
 #pragma unroll 1
         for (int rr = 0; rr < kRows; ++rr) {
             if (rr >= nvalid) break;                                        // wave-uniform
-            const uint32_t *obr = ob + (ptrdiff_t)(rr - r) * row_words;     // row rr's bitstring (this lane's region is row r's)
-            float4 *dst = reinterpret_cast<float4 *>(obs_env + (ptrdiff_t)(rr - r) * obs_row_stride);
+            const uint32_t *obr = ob0 + (ptrdiff_t)rr * row_words;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(obs_wave + (size_t)rr * 12 * WH, 0, D::F4 * 16, 0x00020000);
+            if (wt) {
 #pragma unroll 4
-            for (int j = lane; j < D::F4; j += kWave) dst[j] = tab[(obr[j >> 3] >> sh) & 15u];
+                for (int j = lane; j < D::F4; j += kWave) store_f4<kStoreWriteThrough>(tab[(obr[j >> 3] >> shl) & 15u], rs, j * 16);
+            } else {
+#pragma unroll 4
+                for (int j = lane; j < D::F4; j += kWave) store_f4<kStorePlain>(tab[(obr[j >> 3] >> shl) & 15u], rs, j * 16);
+            }
         }
     }
     if (valid && extra_env && l < 4) {                                      // :238-243: f32(ammo / 6) computed in f64

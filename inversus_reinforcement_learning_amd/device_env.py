@@ -33,9 +33,10 @@ class StepResult:
 
 class DeviceEnvBatch:
     def __init__(self, num_envs, width=15, height=10, max_bullets=16, max_episode_steps=500,
-                 opponent="dummy", difficulty="easy", device=None, opp_seed=0, env_offset=0, step_kernel=None):
+                 opponent="dummy", difficulty="easy", device=None, opp_seed=0, env_offset=0, step_kernel=None, obs_store=None):
         """step_kernel: "auto" (default; env INVERSUS_STEP_KERNEL overrides the default), "wave" or "row4" -- which kernel runs
-        full steps (inv_set_step_kernel); results are identical."""
+        full steps (inv_set_step_kernel); obs_store: "auto" (default; env INVERSUS_OBS_STORE) or "plain" -- the cache policy of
+        the f32 observation stores (inv_set_obs_store_policy).  Results are identical either way."""
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("inversus_reinforcement_learning_amd needs a ROCm GPU (torch.cuda is unavailable); "
@@ -68,6 +69,12 @@ class DeviceEnvBatch:
         if kind != "auto":
             code = {"wave": L.INV_STEP_KERNEL_WAVE, "row4": L.INV_STEP_KERNEL_ROW4}[kind]
             L.raise_for(self.lib.inv_set_step_kernel(self.h, code), self.lib)
+        store = (obs_store or os.environ.get("INVERSUS_OBS_STORE") or "auto").lower()
+        if store not in ("auto", "plain"):
+            raise ValueError(f"obs_store must be auto or plain, got {store!r}")
+        self.obs_store = store
+        if store == "plain":
+            L.raise_for(self.lib.inv_set_obs_store_policy(self.h, L.INV_OBS_STORE_PLAIN), self.lib)
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None

@@ -533,3 +533,47 @@ def test_action_buffers_ending_exactly_at_an_allocation_end(torch_cuda):
     for k in ("grid", "players", "nbullets", "bullets", "step_count"):
         assert np.array_equal(s[k], o[k]), k
     b.check()
+
+
+# ------------------------------------------------------------------ observation store policy (round 3)
+@pytest.mark.parametrize("W,H,n", [(15, 10, 64), (15, 10, 62), (32, 32, 16), (8, 8, 16), (9, 7, 16)])
+def test_observation_store_policies_and_unaligned_buffers_give_identical_bytes(torch_cuda, W, H, n):
+    """inv_set_obs_store_policy is a speed knob: write-through stores (chosen by the library where every store covers whole
+    128-B lines: aligned pointers and 4-env groups on 15x10 / line-multiple regions) and plain stores produce the same
+    observations, also when the caller's buffer is NOT 128-B aligned (the library must fall back to plain stores) and when
+    num_envs is not a multiple of four (the last wave of the four-env kernel writes region by region)."""
+    torch = torch_cuda
+    from inversus_reinforcement_learning_amd.device_env import StepResult
+    outs = {}
+    for tag, store, shift in (("auto", "auto", 0), ("plain", "plain", 0), ("auto, buffer + 16 B", "auto", 4), ("auto, buffer + 64 B", "auto", 16)):
+        b = make(n, W, H, opponent="selfplay", obs_store=store)
+        b.seed(np.arange(n, dtype=np.int64) + 11)
+        b.reset()
+        big = torch.full((2, n * 12 * H * W + 64), -7.0, device="cuda")
+        views = [big[q, shift:shift + n * 12 * H * W].view(n, 12, H, W) for q in range(2)]
+        assert views[0].data_ptr() % 128 == (4 * shift) % 128
+        r0 = b._alloc_out((), True, True, False, None)
+        o = StepResult(**{k: getattr(r0, k) for k in StepResult.__slots__})
+        o.obs, o.obs_p2 = views
+        rng = np.random.RandomState(3)
+        seen = []
+        for t in range(24):
+            a1, a2 = rng.randint(0, 13, n).astype(np.uint8), rng.randint(0, 13, n).astype(np.uint8)
+            b.step(a1, a2, auto_reset=True, out=o)
+            seen.append((o.obs.cpu().numpy().copy(), o.obs_p2.cpu().numpy().copy(), o.reward.cpu().numpy().copy()))
+        b.check()
+        # nothing outside the views was touched
+        assert float(big[:, :shift].sum()) == -7.0 * 2 * shift and bool((big[:, shift + n * 12 * H * W:] == -7.0).all())
+        outs[tag] = seen
+    ref = outs["auto"]
+    for tag, seen in outs.items():
+        for t, (x, y) in enumerate(zip(ref, seen)):
+            assert all(bits_eq(p, q) for p, q in zip(x, y)), (tag, t)
+    # and the rendered observation (inv_render_obs) through both policies
+    for store in ("auto", "plain"):
+        b = make(n, W, H, opponent="selfplay", obs_store=store)
+        b.seed(np.arange(n, dtype=np.int64) + 11)
+        b.reset()
+        g0, _ = b.render(0)
+        outs[store + " render"] = g0.cpu().numpy()
+    assert bits_eq(outs["auto render"], outs["plain render"])

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the two step kernels (wave-per-env vs four envs per wave) on the configurations bench.py reports:
+"""A/B of the two step kernels (wave-per-env vs four envs per wave) and the two observation store policies (plain / auto =
+write-through where line-aligned) on the configurations bench.py reports:
 us per vector step at N = 16384 (HIP events over 256 back-to-back launches, median of 5)."""
 import json, os, sys
 import numpy as np, torch
@@ -21,7 +22,8 @@ def timed(fn, reps=256, warm=64):
     return sorted(out)[2]
 
 def cfg(kind, W, H, opponent, difficulty, obs_p2, bits, T=1):
-    b = DeviceEnvBatch(n, W, H, K, opponent=opponent, difficulty=difficulty, opp_seed=1, step_kernel=kind)
+    kind, store = kind.split("/")
+    b = DeviceEnvBatch(n, W, H, K, opponent=opponent, difficulty=difficulty, opp_seed=1, step_kernel=kind, obs_store=store)
     b.seed(np.arange(n, dtype=np.int64)); b.reset()
     acts = torch.stack([b.uniform_actions(5, t) for t in range(64)])
     a2 = torch.stack([b.uniform_actions(6, t) for t in range(64)]) if opponent == "selfplay" else None
@@ -60,10 +62,16 @@ rows = [("vs_dummy easy 15x10 f32", 15, 10, "dummy", "easy", False, False, 1),
         ("vs_dummy hard 32x32 f32", 32, 32, "dummy", "hard", False, False, 1),
         ("rollout T=32 easy 15x10 f32", 15, 10, "dummy", "easy", False, False, 32),
         ("32 single launches into 32 DISTINCT buffers, easy 15x10 f32", 15, 10, "dummy", "easy", False, False, -32),
-        ("rollout T=32 hard 15x10 PACKED", 15, 10, "dummy", "hard", False, True, 32)]
+        ("rollout T=32 hard 15x10 PACKED", 15, 10, "dummy", "hard", False, True, 32),
+        ("32 DISTINCT buffers, hard 15x10 f32", 15, 10, "dummy", "hard", False, False, -32),
+        ("16 DISTINCT buffers, selfplay 15x10 f32 P1+P2", 15, 10, "selfplay", "easy", True, False, -16),
+        ("4 DISTINCT buffers, hard 32x32 f32", 32, 32, "dummy", "hard", False, False, -4),
+        ("rollout T=4 hard 32x32 f32", 32, 32, "dummy", "hard", False, False, 4)]
 res = {}
 for name, *c in rows:
     if only and not any(o_ in name for o_ in only):
         continue
-    res[name] = {k: cfg(k, *c) for k in ("wave", "row4")}
+    kinds = ("wave/plain", "row4/plain") if c[5] else ("wave/plain", "wave/auto", "row4/plain", "row4/auto")   # packed: no f32 stores
+    res[name] = {k: cfg(k, *c) for k in kinds}
+    torch.cuda.empty_cache()
     print(json.dumps({name: res[name]}), flush=True)
