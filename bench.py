@@ -328,6 +328,77 @@ def side_measurements(torch, np, n):
     return out
 
 
+def c4_iteration(torch, np, dist, n, rank, world, off, backend, T=8):
+    """BASELINE config C4's real workload on this rank's env shard (runs on EVERY rank; collectives inside): a self-play
+    collection of T vector steps (two fused policy forwards per step, no collective), then one PPO epoch over it = T
+    minibatches of n samples, each an optimizer step with the flat-bucket gradient all-reduce (parallel.FlatGradReducer:
+    the heads' 39.3 MB launched before the trunk's backward, the rest after it).  The all-reduce is priced three ways:
+    alone (the bucket's two pieces back to back with nothing else running), EXPOSED (update with the collectives minus the
+    same update with them switched off) and overlapped (alone - exposed).  Times are the MAX over ranks."""
+    from inversus_reinforcement_learning_amd import parallel
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
+
+    def mx(x):
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def fence():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    torch.manual_seed(0)                                                   # the same initial replica on every rank
+    parallel.seed_device_generator(0, rank)                                # ... and a sampling stream of its own per shard
+    b = DeviceEnvBatch(n, opponent="selfplay", env_offset=off)
+    b.seed(off + np.arange(n, dtype=np.int64)); b.reset()
+    agent = PPOAgent(InversusCNNPolicy(12, H, W, 4), fused_act=True, fused_update=True, batch_size=n, epochs=1)
+    if agent.reducer is None:
+        raise RuntimeError("c4_iteration needs an initialised process group (the agent built no gradient reducer)")
+    parallel.broadcast_parameters(agent.policy)
+    agent.fused.refresh()
+    col = RolloutCollector(b, agent, FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval(), actor_only=True))
+    col.collect(T); agent.update()                                         # warm-up (allocator, GEMM heuristics, communicator)
+    fence(); t0 = time.perf_counter()
+    col.collect(T); torch.cuda.synchronize(); t1 = time.perf_counter()
+    dist.barrier(); t1b = time.perf_counter()
+    agent.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    digest_ok = True
+    try:
+        parallel.assert_replicas_in_sync(agent.policy)
+    except RuntimeError:
+        digest_ok = False
+    col.collect(T); agent.reducer.comm = False
+    fence(); t3 = time.perf_counter()
+    agent.update(); torch.cuda.synchronize(); t4 = time.perf_counter()
+    agent.reducer.comm = True
+    flat, ne = agent.reducer.flat, agent.reducer.n_early
+    reps = 10
+    for _ in range(2):
+        dist.all_reduce(flat[:ne]); dist.all_reduce(flat[ne:])
+    fence(); t5 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(flat[:ne]); dist.all_reduce(flat[ne:])
+    torch.cuda.synchronize(); t6 = time.perf_counter()
+    collect_s, upd_s, upd_nc_s, ar_s = mx(t1 - t0), mx(t2 - t1b), mx(t4 - t3), mx(t6 - t5)
+    exposed = (upd_s - upd_nc_s) / T * 1e3
+    alone = ar_s / reps * 1e3
+    b.check()
+    return {"world": world, "backend": backend, "envs_per_rank": n, "rollout_steps": T, "minibatch_per_rank": n,
+            "selfplay_collector_env_steps_per_s": round(world * n * T / collect_s),
+            "update_ms_per_minibatch": round(upd_s / T * 1e3, 3),
+            "update_ms_per_minibatch_collectives_off": round(upd_nc_s / T * 1e3, 3),
+            "allreduce_exposed_ms_per_optimizer_step": round(exposed, 3),
+            "allreduce_alone_ms_per_optimizer_step": round(alone, 3),
+            "allreduce_overlapped_ms_per_optimizer_step": round(max(0.0, alone - max(0.0, exposed)), 3),
+            "gradient_bucket_bytes": int(flat.numel()) * 4, "early_piece_bytes": int(ne) * 4,
+            "train_env_steps_per_s_1_epoch": round(world * n * T / (collect_s + upd_s)),
+            "replicas_identical_after_update": digest_ok}
+
+
 def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks of this script (one per GPU) and wait.
     The parent has not imported torch or touched the GPU, and it never execs: the children are new processes that
@@ -379,6 +450,8 @@ def main():
     ap.add_argument("--difficulty", default="easy", choices=["easy", "hard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--no-c4", action="store_true",
+                    help="N > 1 only: skip the self-play PPO iteration (collector + fused update + gradient all-reduce) extra")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--share-device", action="store_true",
@@ -408,7 +481,9 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:                               # only a forced one-rank group gets here without one
+            from inversus_reinforcement_learning_amd.parallel import free_port
+            os.environ["MASTER_PORT"] = str(free_port())
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
@@ -506,6 +581,19 @@ def main():
     skern_ms_ranks = gather(skern_ms)
     del so, slots, sstep
 
+    # N > 1 (or a forced one-rank group): C4's self-play PPO iteration with the gradient all-reduce, on every rank
+    c4 = None
+    if use_dist and not args.no_c4:
+        del sregions
+        torch.cuda.empty_cache()
+        try:
+            c4 = c4_iteration(torch, np, dist, n, rank, world, off, args.backend)
+        except Exception as exc:                                            # never lose the headline line to the extra
+            c4 = f"failed: {type(exc).__name__}: {exc}"
+            if world > 1:
+                raise
+        torch.cuda.empty_cache()
+
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     med = order[len(order) // 2]                     # the median region by wall time (max over ranks)
     dt, kern_ms = regions[med]
@@ -557,6 +645,8 @@ def main():
             del b, out, a1_all, step
             torch.cuda.empty_cache()
             res["extras"] = side_measurements(torch, np, n)
+        if c4 is not None:
+            res.setdefault("extras", {})["C4 selfplay PPO iteration"] = c4
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

@@ -17,6 +17,25 @@ def world():
     return 0, 1
 
 
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (rendezvous of a single-rank group, or of ranks this process launches)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def seed_device_generator(base, rank):
+    """Give this rank's device generator a stream of its own.  Action sampling (inv_sample_actions takes its Philox key from
+    torch's device generator; the counter is the LOCAL sample index) and the minibatch permutations draw from it, and every
+    process starts it from the same default seed: without this, env i of every shard would see the same uniform at every step.
+    Returns the seed that was set (a function of (base, rank) only, so a run is reproducible from its --seed)."""
+    seed = (int(base) * 0x9E3779B97F4A7C15 + (int(rank) + 1) * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+    return seed
+
+
 def initialized():
     """A process group exists (possibly of ONE rank: INVERSUS_FORCE_DIST=1 runs the collectives' code path -- communicator
     creation, all-reduce launches -- on a single GPU, which is how the RCCL branch is exercised on a 1-GPU box)."""
@@ -32,8 +51,11 @@ def init_from_env(backend=None):
         return world()
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
-    os.environ.setdefault("MASTER_PORT", "29531")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        if ws > 1:
+            raise RuntimeError("WORLD_SIZE > 1 needs MASTER_PORT (torchrun and bench.py's own launcher set it)")
+        os.environ["MASTER_PORT"] = str(free_port())     # a forced ONE-rank group: any free port (two such runs on one host must not collide)
     if backend is None:
         # INVERSUS_DIST_BACKEND=gloo + INVERSUS_SHARE_DEVICE=1 rehearse the multi-rank path on a 1-GPU box
         backend = os.environ.get("INVERSUS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -83,6 +105,9 @@ class FlatGradReducer:
             off += p.numel()
         self._pending, self._work = len(self.early), None
         self._hooks = []
+        # comm = False skips the collectives (measurement only: bench.py times the update with and without them to read the
+        # EXPOSED all-reduce time; the replicas diverge, so never in a training run)
+        self.comm = True
         if initialized():
             for p in self.early:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._early_ready))
@@ -97,13 +122,13 @@ class FlatGradReducer:
 
     def _early_ready(self, _param):
         self._pending -= 1
-        if self._pending == 0 and self._work is None:
+        if self._pending == 0 and self._work is None and self.comm:
             self._work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
 
     def start_early(self):
         """The `early` parameters' gradients are final (written without the autograd engine, so no hook fired): launch their
         all-reduce now; reduce() waits for it."""
-        if initialized() and self.n_early and self._work is None:
+        if initialized() and self.comm and self.n_early and self._work is None:
             self._work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
 
     def zero(self):
@@ -126,7 +151,7 @@ class FlatGradReducer:
         fused Adam kernel)."""
         self._check_aliases()
         _, w = world()
-        if initialized():
+        if initialized() and self.comm:
             if self._work is not None:                      # the heads' part is already travelling (or done)
                 self._work.wait()
                 if self.n_early < self.flat.numel():

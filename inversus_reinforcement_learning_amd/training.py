@@ -147,6 +147,8 @@ def _make(num_envs_total, opponent_type, difficulty, seed, width, height):
         t = torch.tensor([base], dtype=torch.int64, device="cuda")
         torch.distributed.broadcast(t, 0)
         base = int(t.item())
+    if world_size > 1:
+        parallel.seed_device_generator(base, rank)                  # sampling / permutation streams differ between shards
     batch = DeviceEnvBatch(count, width, height, opponent=opponent_type, difficulty=difficulty,
                            opp_seed=base, env_offset=offset)
     batch.seed(base + offset + np.arange(count, dtype=np.int64))    # seed + global env index (env_wrappers.py:463)

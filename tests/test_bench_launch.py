@@ -26,6 +26,29 @@ def parse_line(proc):
     return json.loads(lines[0])
 
 
+def check_streaming_fields(res):
+    """Round 3: the parsed line carries the HBM-streaming regime (32 distinct output buffers) beside the cache-resident loop."""
+    r = res["roofline"]
+    assert "cache-resident" in r["regime"]
+    assert r["kernel_ms_streaming"] > 0 and len(r["kernel_ms_streaming_per_rank"]) == res["n_gpus"]
+    assert r["achieved_streaming"] == pytest.approx(7369 * 16384 / (r["kernel_ms_streaming"] * 1e-3) / 1e9, rel=1e-6)
+    assert r["frac_streaming"] == pytest.approx(r["achieved_streaming"] / r["peak"], rel=1e-9)
+    assert r["value_streaming"] == pytest.approx(res["n_gpus"] * 16384 / (r["ms_per_step_streaming"] * 1e-3), rel=1e-6)
+
+
+def check_c4_entry(res, world, backend):
+    """Round 3: for N > 1 (and a forced one-rank group) rank 0's line prices C4's real workload: self-play collection, the fused
+    update, and the gradient all-reduce per optimizer step (alone / exposed / overlapped)."""
+    c4 = res["extras"]["C4 selfplay PPO iteration"]
+    assert isinstance(c4, dict), c4
+    assert c4["world"] == world and c4["backend"] == backend and c4["envs_per_rank"] == 16384
+    assert c4["gradient_bucket_bytes"] == 10249582 * 4 and 0 < c4["early_piece_bytes"] < c4["gradient_bucket_bytes"]
+    assert c4["selfplay_collector_env_steps_per_s"] > 0 and c4["update_ms_per_minibatch"] > 0
+    assert c4["update_ms_per_minibatch_collectives_off"] > 0 and c4["allreduce_alone_ms_per_optimizer_step"] > 0
+    assert c4["allreduce_overlapped_ms_per_optimizer_step"] >= 0
+    assert c4["replicas_identical_after_update"] is True
+
+
 def test_self_launch_fails_cleanly_without_gpus():
     """CPU: the parent spawns 2 child ranks (no GPU call in the parent); without GPUs each child exits with a message, the
     parent reaps both and returns non-zero instead of hanging in a rendezvous."""
@@ -45,13 +68,16 @@ def test_self_launched_two_ranks_share_the_gpu_over_gloo():
     assert len(res["roofline"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in res["roofline"]["kernel_ms_per_rank"])
     assert abs(res["value"] - 2 * 16384 * 50 / (res["ms_per_step"] * 50e-3)) < 1e-3 * res["value"]
     assert len(res["ms_per_step_repeats"]) == 3 and sorted(res["ms_per_step_repeats"])[1] == pytest.approx(res["ms_per_step"], rel=1e-4)
+    check_streaming_fields(res)
+    check_c4_entry(res, 2, "gloo")
 
 
 @pytest.mark.gpu
 def test_self_launched_four_ranks_share_the_gpu_over_gloo():
     """Four ranks (env shards 0..3 of 16 384 envs each) on the one GPU: the rank arithmetic beyond two ranks."""
     res = parse_line(run_bench("--gpus", "4", "--backend", "gloo", "--share-device", "--steps", "30", "--warmup", "5",
-                               "--repeats", "2", "--no-cpu-baseline", "--no-extras"))
+                               "--repeats", "2", "--no-cpu-baseline", "--no-extras", "--no-c4"))
+    assert "extras" not in res
     assert res["n_gpus"] == 4 and len(res["roofline"]["kernel_ms_per_rank"]) == 4
     assert res["config"]["sharding"].startswith("env-shards x4")
     assert abs(res["value"] - 4 * 16384 * 30 / (res["ms_per_step"] * 30e-3)) < 1e-3 * res["value"]
@@ -63,7 +89,7 @@ def test_external_launcher_is_respected():
     env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
-                        "--steps", "30", "--warmup", "5", "--repeats", "1", "--no-cpu-baseline", "--no-extras"],
+                        "--steps", "30", "--warmup", "5", "--repeats", "1", "--no-cpu-baseline", "--no-extras", "--no-c4"],
                        env=env, cwd=ROOT, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     res = parse_line(p)
     assert res["n_gpus"] == 2 and len(res["roofline"]["kernel_ms_per_rank"]) == 2
@@ -76,6 +102,8 @@ def test_rccl_branch_runs_with_one_rank():
     res = parse_line(run_bench("--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "50", "--warmup", "5", "--repeats", "2",
                                "--no-cpu-baseline", "--no-extras"))
     assert res["n_gpus"] == 1 and res["config"]["backend"] == "nccl" and len(res["roofline"]["kernel_ms_per_rank"]) == 1
+    check_streaming_fields(res)
+    check_c4_entry(res, 1, "nccl")                                    # the flat-bucket all-reduce through RCCL (one rank)
 
 
 @pytest.mark.gpu

@@ -147,3 +147,23 @@ def test_sample_actions_is_categorical_sampling_with_the_loss_kernels_log_probs(
     assert abs(float(means[0]) + float(adv.double().mean())) < 1e-6
     # every row gets its own uniform: a batch of identical rows does not produce identical actions
     assert len(torch.unique(a[:64])) > 1
+
+
+def test_every_rank_gets_a_sampling_stream_of_its_own():
+    """inv_sample_actions keys Philox by torch's device generator and counts by the LOCAL sample index, and every
+    process starts that generator from the same default seed -- so env i of every shard drew the same uniform at every step.
+    training._make now seeds the generator per rank (parallel.seed_device_generator): same (seed, rank) = same stream, another
+    rank = another stream."""
+    import torch
+    from inversus_reinforcement_learning_amd.flat_optim import sample_actions
+    from inversus_reinforcement_learning_amd.parallel import seed_device_generator
+    logits = torch.zeros(8192, 13, device="cuda")
+
+    def stream(base, rank):
+        seed_device_generator(base, rank)
+        return torch.stack([sample_actions(logits)[0] for _ in range(3)])
+
+    a0, a1, a0_again, b0 = stream(7, 0), stream(7, 1), stream(7, 0), stream(8, 0)
+    assert torch.equal(a0, a0_again)
+    assert float((a0 != a1).float().mean()) > 0.85 and float((a0 != b0).float().mean()) > 0.85      # 12/13 expected
+    assert seed_device_generator(7, 0) != seed_device_generator(7, 1)

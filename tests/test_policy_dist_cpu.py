@@ -71,3 +71,26 @@ def test_two_rank_gloo_update_equals_single_process():
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out}"
         assert "DIST_OK" in out, out
+
+
+def test_forced_single_rank_groups_pick_a_free_port(monkeypatch):
+    """a forced one-rank group used a fixed MASTER_PORT (29531 / 29533), so two such runs on one host collided.
+    init_from_env now binds port 0 to find a free one; with WORLD_SIZE > 1 a missing MASTER_PORT is an error, not a guess."""
+    import torch.distributed as dist
+    from inversus_reinforcement_learning_amd import parallel
+    a, b = parallel.free_port(), parallel.free_port()
+    assert 1024 < a < 65536 and 1024 < b < 65536
+    if dist.is_initialized():
+        return
+    for k in ("MASTER_PORT", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        parallel.init_from_env(backend="gloo")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("INVERSUS_FORCE_DIST", "1")
+    assert parallel.init_from_env(backend="gloo") == (0, 1)
+    try:
+        assert parallel.initialized() and int(os.environ["MASTER_PORT"]) > 1024
+    finally:
+        dist.destroy_process_group()
