@@ -68,6 +68,33 @@ def host_threads():
     return aff, quota
 
 
+def thread_placement():
+    """Where the OpenMP threads of the CPU baseline may run and where their memory comes from: the binding policy in force
+    (none unless the environment sets one: threads float over the affinity mask under a CPU-time quota), the allowed CPUs /
+    NUMA nodes, and the node of the calling thread (buffers are first-touched by the threads that write them)."""
+    out = {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
+           "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"), "first_touch": "inside the OpenMP region (each thread faults in the pages it writes)"}
+    try:
+        with open("/proc/self/status") as f:
+            for ln in f:
+                if ln.startswith(("Cpus_allowed_list", "Mems_allowed_list")):
+                    k, v = ln.split(":", 1)
+                    out[k] = v.strip()
+    except OSError:
+        pass
+    try:
+        import ctypes
+        cpu = ctypes.CDLL(None).sched_getcpu()                            # os.sched_getcpu arrives with Python 3.13
+        out["calling_thread_cpu"] = cpu
+        if cpu is not None:
+            import glob
+            nodes = [d for d in glob.glob(f"/sys/devices/system/cpu/cpu{cpu}/node*")]
+            out["calling_thread_numa_node"] = int(os.path.basename(nodes[0])[4:]) if nodes else None
+    except (OSError, AttributeError):
+        pass
+    return out
+
+
 def cpu_baseline(difficulty, budget_s=8.0):
     """The C oracle (bit-checked against the reference) on the host cores: same seeds, same action stream, same
     config; bounded sample.  Threads = what the job may use (affinity / cgroup quota, both reported), the output
@@ -116,6 +143,10 @@ def cpu_baseline(difficulty, budget_s=8.0):
 
     v, steps = run(NUM_ENVS, cores, budget_s)
     v1, _ = run(NUM_ENVS, 1, 3.0)
+    # one thread on a per-thread SLICE of the job (16 384 envs / 16 threads = 1 024 envs: 7.4 MB of observations instead of
+    # 118 MB): the per-core yardstick that all-threads / threads should be compared with -- one thread streaming the whole
+    # 118 MB batch is bound by one core's share of the memory system, which is why all-threads looked super-linear against it
+    v1s, _ = run(max(4, NUM_ENVS // max(1, cores)), 1, 2.0)
     scaling = {"1": round(v1), str(cores): round(v)}
     if cores > 16:
         scaling["16"] = round(run(NUM_ENVS, 16, 3.0)[0])
@@ -131,9 +162,13 @@ def cpu_baseline(difficulty, budget_s=8.0):
             "sample": f"{steps} vector steps x {NUM_ENVS} envs, vs_dummy_{difficulty}, C oracle (OpenMP over envs, static schedule, "
                       "buffers reused and first-touched in the parallel region), obs rendered",
             "env_steps_per_s_by_threads": scaling, "speedup_all_threads_vs_one": round(v / v1, 2),
-            "one_core_env_steps_per_s": round(v1), "n4_one_core_env_steps_per_s": round(v4),
+            "one_core_env_steps_per_s": round(v1),
+            "one_core_on_a_per_thread_slice_env_steps_per_s": round(v1s), "per_thread_slice_envs": max(4, NUM_ENVS // max(1, cores)),
+            "speedup_all_threads_vs_one_on_its_slice": round(v / v1s, 2),
+            "n4_one_core_env_steps_per_s": round(v4),
             "n4_python_object_loop_env_steps_per_s": round(vpy),
-            "host": {"cpu_model": model, "nproc": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota": quota}}
+            "host": {"cpu_model": model, "nproc": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota": quota,
+                     "placement": thread_placement()}}
 
 
 def side_measurements(torch, np, n):

@@ -489,13 +489,17 @@ class MultiEnvRunner:
 
         output="numpy": host arrays and a list of N dicts, exactly like the reference.
         output="torch": device tensors; `infos` is an InfoBatch (device tensors, `infos[i]` builds the
-        reference's dict on demand) and nothing synchronises unless an episode ended this step."""
+        reference's dict on demand); one device->host round trip per step (did any episode end? + the error word)."""
         a2 = self._opponent_actions(opponent_policy)
         res = self.batch.step(action_ids, a2, auto_reset=self.auto_reset)
         if self.output == "torch":
             infos = InfoBatch(res)
             done = res.done.bool()
-            if bool(done.any()):                                          # one scalar D2H; stats only for finished envs
+            any_done = bool(done.any())                                   # the step's ONE device->host round trip ...
+            self.batch.check()                                            # ... the stream is drained, so the sticky error word costs a
+            #                                                               4-byte copy: ValueError on a bad action id like the
+            #                                                               reference (env_wrappers.py:66), also for device tensors
+            if any_done:                                                  # stats only for finished envs
                 idx = done.nonzero().flatten()                            # then ONE gather + D2H per field, not one per env
                 for i, f, n, r in zip(idx.tolist(), res.info_flags[idx].tolist(), res.episode_steps[idx].tolist(),
                                       res.episode_return[idx].tolist()):

@@ -112,6 +112,9 @@ class RolloutCollector:
         (the per-step outputs are fresh tensors, so holding them costs nothing), not one synchronisation per vector step."""
         if not self._pending:
             return
+        # the rollout's one synchronisation point: an invalid action id of ANY step since the last drain raises here like the
+        # reference's ValueError (env_wrappers.py:66) -- not per vector step, which would stall the launch queue
+        self.batch.check()
         done = torch.stack([p[0] for p in self._pending]).bool()                  # [T, N]
         t_idx, e_idx = done.nonzero(as_tuple=True)                                # row-major: step, then env == completion order
         T = len(self._pending)

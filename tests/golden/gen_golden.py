@@ -247,6 +247,8 @@ def gen_dummy(n_cases=3000):
     rng = np.random.RandomState(11)
     env = InversusEnv(seed=5)
     recs = {k: [] for k in ("grid", "players", "hard", "u", "perm_a", "swap_c", "perm_b", "action")}
+    HIST_REPS = 200
+    hist = [np.zeros((n_cases, 13), np.uint16), np.zeros((n_cases, 13), np.uint16)]
     real_random, real_shuffle = random.random, random.shuffle
 
     def skewed():
@@ -302,12 +304,26 @@ def gen_dummy(n_cases=3000):
             recs["grid"].append(grid_words(env)); recs["players"].append(player_rows(env))
             recs["hard"].append(hard); recs["u"].append(u); recs["perm_a"].append(perm_a)
             recs["swap_c"].append(swap_c); recs["perm_b"].append(perm_b); recs["action"].append(aid)
+            # G6 as SURVEY 8(c) words it: the action HISTOGRAM of the reference's own dummy_opponent_policy on this fixed state,
+            # with the real (seeded) global `random`, both difficulties -- what the device dummy's counter-hash draws are
+            # compared with by a chi-square test (tests/test_gpu_dummy_hist.py).  The global generator's state is restored.
+            saved = random.getstate()
+            random.seed(99991 + c)
+            for di, dname in enumerate(("easy", "hard")):
+                for _ in range(HIST_REPS):
+                    a = ew.dummy_opponent_policy(env, difficulty=dname)
+                    hid = 0 if a.type == ActionType.NONE else (1 if a.type == ActionType.MOVE else 5) + DIR_IDX.get(a.direction, 0)
+                    hist[di][c, hid] += 1
+            random.setstate(saved)
             env.player2.alive = True      # undo a forced death; real deaths were reset above
     finally:
         random.random, random.shuffle = real_random, real_shuffle
     arr = {k: np.array(v) for k, v in recs.items()}
     np.savez_compressed(os.path.join(OUT, "g6_dummy.npz"), **arr)
     print("g6 dummy action histogram:", np.bincount(arr["action"], minlength=13))
+    # a file of its own, so that g6_dummy.npz stays byte-identical to round 1's; rows line up with g6_dummy.npz's states
+    np.savez_compressed(os.path.join(OUT, "g6_dummy_hist.npz"), hist_easy=hist[0], hist_hard=hist[1], reps=np.int32(HIST_REPS))
+    print("g6 reference histograms (all states): easy", hist[0].sum(0, dtype=np.int64), "hard", hist[1].sum(0, dtype=np.int64))
 
 
 # --------------------------------------------------------------------------- G5
@@ -500,6 +516,8 @@ def main():
     if only:
         if "g8" in only:
             gen_ppo_update()
+        if "g6" in only:
+            gen_dummy()
         if "g3_32" in only:
             gen_wrapper_trace("32x32_biased", 32, 32, 8, 384, base_seed=900, act_seed=203, biased=True, max_steps=150, hunt=(0.6, 0.45))
         return

@@ -180,6 +180,45 @@ def test_runner_torch_output_mode():
             assert inf_t[int(i)] == inf_n[int(i)]
     assert rt.episode_lengths == rn.episode_lengths and rt.episode_wins == rn.episode_wins
     rt.batch.check()
+    # a bad action id in a DEVICE tensor raises like the reference (env_wrappers.py:66) on that very step (the step's one
+    # device->host round trip also reads the error word), leaves the offending env untouched and the runner usable
+    before = rt.batch.get_state()
+    bad = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    bad[5] = 13
+    with pytest.raises(ValueError, match="Invalid action_id"):
+        rt.step(bad)
+    after = rt.batch.get_state()
+    assert np.array_equal(before["players"][5], after["players"][5]) and before["step_count"][5] == after["step_count"][5]
+    rt.step(torch.zeros(n, dtype=torch.uint8, device="cuda"))
+
+
+def test_rollout_collector_raises_on_bad_action_ids_at_the_drain():
+    """The collector never synchronises per vector step; an invalid action id (here: a policy stub that emits 13) surfaces as the
+    reference's ValueError at the rollout's drain (training.py RolloutCollector._drain)."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    n = 64
+
+    class Agent:
+        fused = None
+
+        def __init__(self):
+            self.stored = 0
+
+        def act(self, grid, extra, with_u8=False):
+            a = torch.full((n,), 13 if self.stored == 2 else 1, dtype=torch.int64, device="cuda")
+            z = torch.zeros(n, device="cuda")
+            return (a, z, z, None) if with_u8 else (a, z, z)
+
+        def store_batch(self, *a):
+            self.stored += 1
+
+    b = DeviceEnvBatch(n, opponent="dummy")
+    b.seed(np.arange(n, dtype=np.int64)); b.reset()
+    col = RolloutCollector(b, Agent(), packed_obs=False)
+    with pytest.raises(ValueError, match="Invalid action_id"):
+        col.collect(4)
 
 
 def test_numpy_mode_returns_independent_arrays_every_step():
