@@ -270,7 +270,18 @@ def side_measurements(torch, np, n):
         r = torch.randn(T, n, device="cuda"); v = torch.randn(T, n, device="cuda")
         d = (torch.rand(T, n, device="cuda") < 0.03).to(torch.uint8)
         us = timed(lambda: gae(r, v, d, layout="per_env"), 20)
-        return {"T": T, "us_incl_wrapper": round(us, 2), "GBps": round(17 * T * n / us / 1e3, 1)}
+        # the kernel alone: one pre-marshalled ctypes call per launch (the wrapper's allocations cost more host time than the
+        # kernel runs, so the figure above is host-bound)
+        import ctypes as C
+        from inversus_reinforcement_learning_amd import _lib as L
+        lib = L.load()
+        adv, ret = torch.empty_like(r), torch.empty_like(r)
+        args = (C.c_void_p(r.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(d.data_ptr()), T, n, float(np.float32(0.99)),
+                float(np.float32(0.99 * 0.95)), None, L.INV_GAE_PER_ENV, C.c_void_p(adv.data_ptr()), C.c_void_p(ret.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        usk = timed(lambda: lib.inv_gae(*args), 200, warm=20)
+        return {"T": T, "us_incl_wrapper": round(us, 2), "us_kernel_back_to_back": round(usk, 2), "GBps": round(17 * T * n / usk / 1e3, 1),
+                "frac_of_8000_GBps": round(17 * T * n / usk / 1e3 / HBM_PEAK_GBS, 3)}
     guard("gae per_env T=128", gae_cfg)
 
     def policy_cfg():

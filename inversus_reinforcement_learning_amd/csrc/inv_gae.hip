@@ -8,9 +8,9 @@
 //     ret = A + V[k]
 // The recurrence is sequential by nature; parallelism comes from independent chains.
 //
-//  * per_env: [T][N] buffers, one chain per env column; tiles of 32 columns x 128 steps are
-//    staged through LDS by a whole 256-thread block so that enough memory operations are in
-//    flight (see k_gae_per_env).  HBM-bound in principle: 17 B per transition.
+//  * per_env: [T][N] buffers, one chain per env column; a 512-thread block owns 64 columns and splits
+//    128-step tiles over its 8 waves by time, everything in registers (see k_gae_per_env).
+//    HBM-bound in principle: 17 B per transition.
 //  * reference_flat: the reference scans ONE chain over the env-interleaved buffer
 //    (training.py:128-137 fill order), so V[k+1] is the next env at the same timestep.  A
 //    `done` cuts the chain, so the buffer splits into independent segments, each ending at a
@@ -37,77 +37,87 @@ __device__ __forceinline__ float gae_step(float r, float v, float vnext, bool do
     return last;
 }
 
-// per_env scan, tiled through LDS.  Only N independent chains exist (one per env): with one lane per
-// chain the kernel runs 256 waves at N = 16 384, one per CU, bound by that wave's memory latency and by
-// the per-step dependent code (measured 1.5-1.7 TB/s).  So a 256-thread block owns a tile of
-// kGaeE = 32 env columns x kGaeT = 128 time steps and splits the work by what is truly sequential:
-//   1. all four waves stream r, V (plus the V row of step t+1) and done into LDS (coalesced 128-B rows);
-//   2. all threads compute, in parallel, the part of every step that does not depend on the chain:
-//        e = done ? r - V : (r + gamma*V') - V            (same roundings as the reference, in order)
-//   3. the first 32 lanes run the chains: A = done ? e : e + gamma_lam*A'  -- one multiply, one add and
-//      one select per step, LDS reads unrolled ahead of the dependent ops;
-//   4. all threads form ret = A + V and stream A, ret back.
-// ~69 KB of LDS per block -> two blocks per CU; T > 128 loops over tiles from the end carrying A'.
-constexpr int kGaeT = 128, kGaeE = 32, kGaeThreads = 256, kGaeRowsPerPass = kGaeThreads / kGaeE;
+// per_env scan.  Only N independent chains exist (one per env column of the [T][N] buffers) and a chain is sequential by
+// contract (every step's roundings are the reference's), so one lane per chain alone means 256 waves at N = 16 384, one per CU,
+// each bound by its own memory latency (measured 1.5-1.7 TB/s).  Round 1 staged 32-column x 128-step tiles through LDS (12.9 us
+// for 35.7 MB: load / precompute / chain / write-back phases of all blocks in lockstep, 69 KB of LDS traffic per tile each way).
+// Round 3 keeps everything in REGISTERS and splits a tile over the waves of a block by TIME:
+//   * a block owns 64 env columns (lane = column: every global access is a 256-B row piece) and tiles of kGaeT = 128 steps;
+//     wave w owns the tile's rows [16 w, 16 w + 16) (row k <-> time step thi - k, row 0 = the latest step);
+//   * every wave first requests ALL its rows (r, V, done: 48 loads + the V row of the step after its slice) -- 8 waves x 49
+//     loads = 100 KB in flight per CU -- and computes the chain-independent part of every step in parallel:
+//         e = done ? r - V : (r + gamma*V') - V                        (same roundings as the reference, in order)
+//   * the chain A = done ? e : e + gamma_lam*A' then runs through the waves in turn (wave 0 holds the latest steps): 16
+//     dependent steps per wave, the carry handed on through one LDS word per column and a workgroup barrier;
+//   * a wave streams its A and ret = A + V rows out AFTER handing the carry on, i.e. while the next wave runs its steps.
+// T > 128 loops over tiles from the end; the carry stays in LDS.
+constexpr int kGaeT = 128, kGaeWaves = 8, kGaeRows = kGaeT / kGaeWaves, kGaeCols = 64, kGaeThreads = kGaeWaves * 64;
 
 __global__ __launch_bounds__(kGaeThreads) void k_gae_per_env(const float *__restrict__ r, const float *__restrict__ v,
                                                               const uint8_t *__restrict__ done, int T, int N, float gamma,
                                                               float gl, const float *__restrict__ last_value,
                                                               float *__restrict__ adv, float *__restrict__ ret)
 {
-    __shared__ float se[kGaeT][kGaeE];           // r, then e (step 2), then A (step 3)
-    __shared__ float sv[kGaeT + 1][kGaeE];       // sv[k + 1] = V at tile row k; sv[0] = V of the step after the tile
-    __shared__ uint8_t sd[kGaeT][kGaeE];
-    const int tid = threadIdx.x;
-    const int i0 = blockIdx.x * kGaeE;
-    const int c = tid & (kGaeE - 1), k0 = tid / kGaeE;           // this thread's column and first tile row
-    const bool col_ok = i0 + c < N;
-    const bool chain = tid < kGaeE && col_ok;
-    float last = 0.0f;
+    __shared__ float carry[kGaeCols];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * kGaeCols + lane;
+    const bool col_ok = col < N;
+    const int colc = col_ok ? col : N - 1;                      // clamped: out-of-range lanes load a valid column and never store
+    if (w == 0) carry[lane] = 0.0f;                             // last_gae = 0 (ppo_agent.py:141)
 
     for (int thi = T - 1; thi >= 0; thi -= kGaeT) {
-        const int rows = min(kGaeT, thi + 1);                 // tile row k <-> time step thi - k
-        if (col_ok) {
-            if (k0 == 0) sv[0][c] = (thi + 1 < T) ? v[(size_t)(thi + 1) * N + i0 + c] : (last_value ? last_value[i0 + c] : 0.0f);
-#pragma unroll 8
-            for (int k = k0; k < rows; k += kGaeRowsPerPass) {
-                const size_t idx = (size_t)(thi - k) * N + i0 + c;
-                se[k][c] = r[idx]; sv[k + 1][c] = v[idx]; sd[k][c] = done[idx];
+        const int rows = min(kGaeT, thi + 1);
+        const int k0 = w * kGaeRows;                            // my first tile row
+        const int nr = max(0, min(kGaeRows, rows - k0));        // my rows in this tile (wave-uniform)
+        float rr[kGaeRows], vv[kGaeRows], e[kGaeRows];
+        uint32_t dd[kGaeRows];
+        const int tn = thi - k0 + 1;                            // the step after my latest row (<= T; may be < 1 for an idle wave)
+        const float *vnp = (tn < T || !last_value) ? v + (size_t)min(max(tn, 0), T - 1) * N + colc : last_value + colc;
+        float vnext = *vnp;
+        if (tn >= T && !last_value) vnext = 0.0f;
+        // branch-free: rows beyond the tile's end (only in a last, partial tile) load step 0 again and are never used -- a load
+        // inside a conditional block makes hipcc drain vmcnt at the block's end, i.e. one memory round trip per row
+#pragma unroll
+        for (int j = 0; j < kGaeRows; ++j) {
+            const size_t idx = (size_t)max(thi - k0 - j, 0) * N + colc;
+            rr[j] = r[idx]; vv[j] = v[idx]; dd[j] = done[idx];
+        }
+#pragma unroll
+        for (int j = 0; j < kGaeRows; ++j) {
+            const float vn = j == 0 ? vnext : vv[j - 1];
+            const float gv = gamma * vn;
+            const float sum = rr[j] + gv;
+            const float d_nd = sum - vv[j];                     // (r + gamma*V') - V
+            const float d_d = rr[j] - vv[j];                    // r - V
+            e[j] = dd[j] ? d_d : d_nd;
+        }
+        __syncthreads();                                        // carry of the previous tile (or its initial 0) is visible
+#pragma unroll 1
+        for (int p = 0; p < kGaeWaves; ++p) {
+            if (p * kGaeRows >= rows) break;                    // block-uniform
+            if (w == p) {
+                float last = carry[lane];
+#pragma unroll
+                for (int j = 0; j < kGaeRows; ++j) {
+                    const float g2 = gl * last;
+                    const float cand = e[j] + g2;
+                    const float nl = dd[j] ? e[j] : cand;
+                    last = j < nr ? nl : last;
+                    e[j] = last;                                // e becomes A
+                }
+                carry[lane] = last;
+            }
+            __syncthreads();
+            if (w == p && col_ok) {
+#pragma unroll
+                for (int j = 0; j < kGaeRows; ++j) {
+                    if (j < nr) {
+                        const size_t idx = (size_t)(thi - k0 - j) * N + col;
+                        adv[idx] = e[j]; ret[idx] = e[j] + vv[j];
+                    }
+                }
             }
         }
-        __syncthreads();
-        if (col_ok) {
-#pragma unroll 8
-            for (int k = k0; k < rows; k += kGaeRowsPerPass) {
-                const float rr = se[k][c], vv = sv[k + 1][c], vn = sv[k][c];
-                const float gv = gamma * vn;
-                const float sum = rr + gv;
-                const float d_nd = sum - vv;                  // (r + gamma*V') - V
-                const float d_d = rr - vv;                    // r - V
-                se[k][c] = sd[k][c] ? d_d : d_nd;
-            }
-        }
-        __syncthreads();
-        if (chain) {
-#pragma unroll 16
-            for (int k = 0; k < rows; ++k) {
-                const float e = se[k][tid];
-                const float g2 = gl * last;
-                const float cand = e + g2;
-                last = sd[k][tid] ? e : cand;
-                se[k][tid] = last;
-            }
-        }
-        __syncthreads();
-        if (col_ok) {
-#pragma unroll 8
-            for (int k = k0; k < rows; k += kGaeRowsPerPass) {
-                const size_t idx = (size_t)(thi - k) * N + i0 + c;
-                const float a = se[k][c];
-                adv[idx] = a; ret[idx] = a + sv[k + 1][c];
-            }
-        }
-        __syncthreads();                                      // se / sv / sd are rewritten by the next tile
     }
 }
 
@@ -141,7 +151,7 @@ extern "C" int inv_gae(const float *r, const float *v, const uint8_t *done, int3
     if (!r || !v || !done || !adv || !ret || T < 1 || N < 1) return INV_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (layout == INV_GAE_PER_ENV) {
-        hipLaunchKernelGGL(k_gae_per_env, dim3((N + kGaeE - 1) / kGaeE), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
+        hipLaunchKernelGGL(k_gae_per_env, dim3((N + kGaeCols - 1) / kGaeCols), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
     } else if (layout == INV_GAE_REFERENCE_FLAT) {
         const long long n = (long long)T * N;
         hipLaunchKernelGGL(k_gae_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r, v, done, n, gamma, gamma_lam, last_value, adv, ret);

@@ -545,7 +545,9 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
 // Board-generic trunk for boards whose activations do not fit LDS ("banded"; SURVEY.md 8f row N1 for BASELINE config C5:
 // 32 x 32 is 262 KB of bf16 activations per layer and sample).  Per sample and layer the board is processed in BANDS of R
 // rows: the band's input (R + 2 rows with halo) is built in the LDS tile -- layer 1 from the observation, later layers from the
-// previous layer's PRE-norm output z (bf16 channels-last in a per-workgroup scratch that stays in L2 / Infinity Cache) with
+// previous layer's PRE-norm output z (bf16 channels-last in a per-workgroup scratch: 2 x 262 KB per workgroup, 268 MB for the
+// 2 x 256 resident workgroups -- as large as the whole Infinity Cache, so it is cache-assisted L2 / HBM traffic, not resident;
+// the host side keeps ONE scratch per device and stream for all policies, fused_policy.py) with
 // LayerNorm + affine + ReLU applied on the way in, which is possible because a layer's statistics are complete before the
 // next layer starts -- then the same implicit GEMM as above runs on the band (tiles of 16 pixels = pieces of board rows: no
 // dummy columns, conflict-free on the 288-B stride), the statistics are accumulated from the f32 accumulators, and z goes back

@@ -139,3 +139,52 @@ class FlatAdam:
                                              float(grad_scale), _ptr(self.workspace), _stream())
         L.raise_for(rc, self.lib)
         return self.workspace[-8:-4].view(torch.float32)[0]
+
+
+class FlatAdamHandle:
+    """What `agent.optimizer` is while the fused update runs: the torch.optim surface that code around a PPO agent actually
+    touches -- `param_groups[0]["lr"]` (read / write: it IS FlatAdam's learning rate), `state_dict()` / `load_state_dict()`
+    (Adam's moments and step count, so a checkpoint of the optimizer is a checkpoint of the optimizer that steps) and
+    `zero_grad()` -- over FlatAdam's flat buffers.  There is no `step()`: the update calls FlatAdam.step() itself, and an
+    accidental second optimizer stepping the same parameters would be a silent bug."""
+
+    class _Group(dict):
+        def __init__(self, adam):
+            super().__init__(params=adam.params, betas=adam.betas, eps=adam.eps, weight_decay=0.0)
+            self._adam = adam
+
+        def __getitem__(self, k):
+            return self._adam.lr if k == "lr" else super().__getitem__(k)
+
+        def __setitem__(self, k, v):
+            if k == "lr":
+                self._adam.lr = float(v)
+            else:
+                super().__setitem__(k, v)
+
+        def get(self, k, default=None):
+            return self._adam.lr if k == "lr" else super().get(k, default)
+
+    def __init__(self, adam):
+        self.adam = adam
+        self.param_groups = [self._Group(adam)]
+
+    def zero_grad(self, set_to_none=False):
+        self.adam.zero_grad()                                            # never to None: the gradients alias the flat bucket
+
+    def state_dict(self):
+        a = self.adam
+        return {"kind": "FlatAdam", "lr": a.lr, "betas": tuple(a.betas), "eps": a.eps, "max_grad_norm": a.max_grad_norm,
+                "steps": a.steps, "exp_avg": a.exp_avg.detach().clone(), "exp_avg_sq": a.exp_avg_sq.detach().clone()}
+
+    def load_state_dict(self, sd):
+        a = self.adam
+        if sd.get("kind") != "FlatAdam" or sd["exp_avg"].numel() != a.n:
+            raise ValueError("not a FlatAdam state of this parameter set")
+        a.lr, a.betas, a.eps, a.max_grad_norm = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"]), float(sd["max_grad_norm"])
+        a.steps = int(sd["steps"])
+        a.exp_avg.copy_(sd["exp_avg"].to(a.exp_avg.device))
+        a.exp_avg_sq.copy_(sd["exp_avg_sq"].to(a.exp_avg_sq.device))
+
+    def step(self, *a, **k):
+        raise RuntimeError("the fused update steps FlatAdam inside PPOAgent.update(); agent.optimizer.step() would step the parameters twice")

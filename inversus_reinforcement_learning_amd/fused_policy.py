@@ -89,11 +89,10 @@ class FusedPolicy:
         if self.banded and self.train_numerics:
             raise ValueError("the fused update (and its rollout numerics) exists for the 15 x 10 board only")
         if self.banded:
-            nbytes = int(self.lib.inv_policy_trunk_banded_scratch_bytes(self.H, self.W))
-            if nbytes <= 0:
+            with torch.cuda.device(dev):                                 # the size depends on the CU count of THIS device
+                self._scratch_bytes = int(self.lib.inv_policy_trunk_banded_scratch_bytes(self.H, self.W))
+            if self._scratch_bytes <= 0:
                 raise ValueError(f"no fused trunk for a {self.W} x {self.H} board")
-            if getattr(self, "_scratch", None) is None or self._scratch.numel() < nbytes:
-                self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._keep = []
         params = L.InvPolicyParams()
         for i, (conv, norm) in enumerate(((p.conv1, p.norm1), (p.conv2, p.norm2), (p.conv3, p.norm3), (p.conv4, p.norm4))):
@@ -120,6 +119,19 @@ class FusedPolicy:
         self.b1 = torch.cat([m.bias for m in firsts]).detach().float()
         self.hidden = p.fc_actor[0].out_features
 
+    # The banded kernel's per-workgroup z scratch (268 MB on a 256-CU part).  It is only live inside one launch, and launches of
+    # one stream run one after the other, so every policy on a (device, stream) pair shares ONE buffer (the learner and the frozen
+    # self-play opponent used to hold one each: 0.5 GB).
+    _banded_scratch = {}
+
+    @classmethod
+    def _scratch_for(cls, device, nbytes):
+        key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+        buf = cls._banded_scratch.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = cls._banded_scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return buf
+
     @torch.no_grad()
     def features(self, grid):
         """Trunk only: bf16 [B, H*W*128] in channels-last order.  `grid`: f32 planes [B,12,H,W] or the packed
@@ -137,8 +149,9 @@ class FusedPolicy:
         with torch.cuda.device(grid.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             if self.banded:
+                scratch = self._scratch_for(grid.device, self._scratch_bytes)
                 rc = self.lib.inv_policy_trunk_banded(C.byref(self.params), C.c_void_p(grid.data_ptr()), int(bits), self.H, self.W,
-                                                      C.c_void_p(feat.data_ptr()), C.c_void_p(self._scratch.data_ptr()), self._scratch.numel(),
+                                                      C.c_void_p(feat.data_ptr()), C.c_void_p(scratch.data_ptr()), scratch.numel(),
                                                       grid.shape[0], st)
             elif self.train_numerics:
                 rc = self.lib.inv_policy_trunk_train_fwd(C.byref(self.params), C.c_void_p(grid.data_ptr()), int(bits),

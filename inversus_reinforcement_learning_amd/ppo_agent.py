@@ -56,6 +56,10 @@ class PPOAgent:
             order = self.reducer.params if self.reducer is not None else [p for p in self.policy.parameters() if p.requires_grad]
             self.flat_adam = FlatAdam(order, lr=lr, max_grad_norm=max_grad_norm,
                                       grad_flat=self.reducer.flat if self.reducer is not None else None)
+            # the torch Adam built above would never be stepped: agent.optimizer becomes a handle on the optimizer that IS
+            # (learning rate through param_groups, moments / step count through state_dict)
+            from .flat_optim import FlatAdamHandle
+            self.optimizer = FlatAdamHandle(self.flat_adam)
         # every parameter gets its gradient from the fused kernels: the update then bypasses the autograd engine (loss_and_grads)
         self.direct_grads = False
         if fused_update:

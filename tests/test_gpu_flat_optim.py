@@ -167,3 +167,35 @@ def test_every_rank_gets_a_sampling_stream_of_its_own():
     assert torch.equal(a0, a0_again)
     assert float((a0 != a1).float().mean()) > 0.85 and float((a0 != b0).float().mean()) > 0.85      # 12/13 expected
     assert seed_device_generator(7, 0) != seed_device_generator(7, 1)
+
+
+def test_agent_optimizer_is_a_handle_on_the_optimizer_that_steps():
+    """with fused_update the agent used to keep a torch Adam that was never stepped -- changing its learning rate
+    had no effect and checkpointing it lost Adam's state.  agent.optimizer is now a handle on FlatAdam."""
+    import torch
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    torch.manual_seed(0)
+    agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), lr=3e-4, fused_update=True, batch_size=64, epochs=1)
+    opt = agent.optimizer
+    assert opt.param_groups[0]["lr"] == pytest.approx(3e-4) and agent.flat_adam.lr == pytest.approx(3e-4)
+    for g in opt.param_groups:                                            # the usual scheduler idiom
+        g["lr"] = 1e-5
+    assert agent.flat_adam.lr == pytest.approx(1e-5)
+    with pytest.raises(RuntimeError):
+        opt.step()
+    agent.flat_adam.grad.normal_()
+    agent.flat_adam.step()
+    sd = opt.state_dict()
+    assert sd["steps"] == 1 and float(sd["exp_avg"].abs().sum()) > 0
+    before = agent.flat_adam.flat.clone()
+    agent.flat_adam.grad.normal_()
+    agent.flat_adam.step()
+    after_two = agent.flat_adam.flat.clone()
+    # restore the state after step 1 and the parameters, replay step 2 with the same gradient: same result
+    g2 = agent.flat_adam.grad.clone()
+    opt.load_state_dict(sd)
+    agent.flat_adam.flat.copy_(before)
+    agent.flat_adam.grad.copy_(g2)
+    agent.flat_adam.step()
+    assert agent.flat_adam.steps == 2 and torch.equal(agent.flat_adam.flat, after_two)
