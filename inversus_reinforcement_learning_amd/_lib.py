@@ -54,6 +54,10 @@ class InvPolicySaved(C.Structure):
     _fields_ = [("xhat", C.c_void_p * 4), ("act", C.c_void_p * 3), ("rstd", C.c_void_p)]
 
 
+class InvPolicyBandSaved(C.Structure):
+    _fields_ = [("z", C.c_void_p * 4), ("stats", C.c_void_p)]
+
+
 class InvPolicyBwdParams(C.Structure):
     _fields_ = [("wt", C.c_void_p * 3), ("ln", C.c_void_p * 4)]
 
@@ -120,6 +124,13 @@ SIGNATURES = {
     "inv_policy_trunk_banded_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "inv_policy_trunk_banded": (C.c_int, [P(InvPolicyParams), _V, C.c_int32, C.c_int32, C.c_int32, _V, _V, C.c_int64, C.c_int32, _V]),
     "inv_policy_obs_to_x0": (C.c_int, [_V, C.c_int32, _V, C.c_int32, _V]),
+    "inv_policy_trunk_banded_train_fwd": (C.c_int, [P(InvPolicyParams), _V, C.c_int32, C.c_int32, C.c_int32, _V, P(InvPolicyBandSaved), C.c_int32, _V]),
+    "inv_policy_band_ln_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, _V, _V, C.c_int32, _V]),
+    "inv_policy_band_conv_t": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
+    "inv_policy_band_act": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
+    "inv_policy_band_wgrad": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
+    "inv_policy_band_param_grads": (C.c_int, [C.c_int32, _V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V]),
+    "inv_policy_obs_to_x0_any": (C.c_int, [_V, C.c_int32, C.c_int32, _V, C.c_int32, _V]),
     "inv_heads_pack": (C.c_int, [P(InvHeadsPackList), C.c_int32, _V]),
     "inv_heads_pack_fc1": (C.c_int, [_V, C.c_int32, C.c_int32, _V, _V, _V]),
     "inv_heads_unpack_fc1_grad": (C.c_int, [_V, _V, C.c_int32, C.c_int32, _V, _V]),

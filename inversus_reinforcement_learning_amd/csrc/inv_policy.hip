@@ -751,9 +751,12 @@ __device__ __forceinline__ void band_stats(float s, float ss, float cnt, float *
     shift = -mean * rstd;
 }
 
-template <int HB, int WB, int R, bool BITS>
+// SAVE (training forward, BASELINE config C5 with the fused update): the layers' pre-norm outputs z go to per-sample tensors
+// sv.z[l] ([N][P][C_l] bf16 channels-last) instead of the per-workgroup scratch, and the LayerNorm statistics to sv.stats
+// ([N][4][2] f32: rstd, shift = -mean * rstd) -- everything the backward kernels below need; same arithmetic, same features.
+template <int HB, int WB, int R, bool BITS, bool SAVE = false>
 __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_params prm, const void *__restrict__ obs_in, bf16 *__restrict__ feat,
-                                                                     bf16 *__restrict__ scratch, int N)
+                                                                     bf16 *__restrict__ scratch, int N, inv_policy_band_saved sv)
 {
     using G = BandGeo<HB, WB, R>;
     __shared__ __attribute__((aligned(16))) bf16 tile[G::NPOSB * CSF];
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
     __shared__ uint32_t obw[BITS ? G::OWB : 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
-    bf16 *const zA = scratch + (size_t)blockIdx.x * 2 * G::P * 128, *const zB = zA + (size_t)G::P * 128;
+    bf16 *const zA0 = SAVE ? nullptr : scratch + (size_t)blockIdx.x * 2 * G::P * 128, *const zB0 = SAVE ? nullptr : zA0 + (size_t)G::P * 128;
     for (int i = tid; i < G::NPOSB * CSF / 8; i += THREADS) {
         bf16x8 z;
 #pragma unroll
@@ -777,6 +780,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
             for (int w = tid; w < G::OWB; w += THREADS) obw[BITS ? w : 0] = reinterpret_cast<const uint32_t *>(obs_in)[(size_t)n * G::OWB + w];
             __syncthreads();
         }
+        // where the four layers' z live: two ping-pong scratch buffers, or (SAVE) this sample's slices of the saved tensors
+        bf16 *const z1 = SAVE ? reinterpret_cast<bf16 *>(sv.z[0]) + (size_t)n * G::P * 32 : zA0;
+        bf16 *const z2 = SAVE ? reinterpret_cast<bf16 *>(sv.z[1]) + (size_t)n * G::P * 64 : zB0;
+        bf16 *const z3 = SAVE ? reinterpret_cast<bf16 *>(sv.z[2]) + (size_t)n * G::P * 128 : zA0;
+        bf16 *const z4 = SAVE ? reinterpret_cast<bf16 *>(sv.z[3]) + (size_t)n * G::P * 128 : zB0;
         float s, ss, rstd, shift;
         // layer 1: 12 (-> 32) -> 32 channels
         s = ss = 0.0f;
@@ -784,36 +792,40 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         for (int band = 0; band < G::NB; ++band) {
             band_load_obs<G, R, BITS>(tile, obw, planes, band);
             __syncthreads();
-            band_conv<G, R, 32, 32, 1, G::NT / 2, false>(prm.layer[0], tile, zA, band, lane_i, wave & 1, (wave >> 1) * (G::NT / 2), s, ss);
+            band_conv<G, R, 32, 32, 1, G::NT / 2, false>(prm.layer[0], tile, z1, band, lane_i, wave & 1, (wave >> 1) * (G::NT / 2), s, ss);
         }
         band_stats(s, ss, (float)(32 * G::P), red, rstd, shift);
+        if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 0] = rstd; sv.stats[(size_t)n * 8 + 1] = shift; }
         // layer 2: 32 -> 64
         s = ss = 0.0f;
 #pragma unroll 1
         for (int band = 0; band < G::NB; ++band) {
-            band_load_norm<G, R, 32>(tile, zA, prm.layer[0].ln, rstd, shift, band);
+            band_load_norm<G, R, 32>(tile, z1, prm.layer[0].ln, rstd, shift, band);
             __syncthreads();
-            band_conv<G, R, 32, 64, 1, G::NT, false>(prm.layer[1], tile, zB, band, lane_i, wave, 0, s, ss);
+            band_conv<G, R, 32, 64, 1, G::NT, false>(prm.layer[1], tile, z2, band, lane_i, wave, 0, s, ss);
         }
         band_stats(s, ss, (float)(64 * G::P), red, rstd, shift);
+        if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 2] = rstd; sv.stats[(size_t)n * 8 + 3] = shift; }
         // layer 3: 64 -> 128
         s = ss = 0.0f;
 #pragma unroll 1
         for (int band = 0; band < G::NB; ++band) {
-            band_load_norm<G, R, 64>(tile, zB, prm.layer[1].ln, rstd, shift, band);
+            band_load_norm<G, R, 64>(tile, z2, prm.layer[1].ln, rstd, shift, band);
             __syncthreads();
-            band_conv<G, R, 64, 128, 2, G::NT, false>(prm.layer[2], tile, zA, band, lane_i, wave * 2, 0, s, ss);
+            band_conv<G, R, 64, 128, 2, G::NT, false>(prm.layer[2], tile, z3, band, lane_i, wave * 2, 0, s, ss);
         }
         band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
+        if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 4] = rstd; sv.stats[(size_t)n * 8 + 5] = shift; }
         // layer 4: 128 -> 128, + residual
         s = ss = 0.0f;
 #pragma unroll 1
         for (int band = 0; band < G::NB; ++band) {
-            band_load_norm<G, R, 128>(tile, zA, prm.layer[2].ln, rstd, shift, band);
+            band_load_norm<G, R, 128>(tile, z3, prm.layer[2].ln, rstd, shift, band);
             __syncthreads();
-            band_conv<G, R, 128, 128, 2, G::NT, true>(prm.layer[3], tile, zB, band, lane_i, wave * 2, 0, s, ss);
+            band_conv<G, R, 128, 128, 2, G::NT, true>(prm.layer[3], tile, z4, band, lane_i, wave * 2, 0, s, ss);
         }
         band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
+        if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 6] = rstd; sv.stats[(size_t)n * 8 + 7] = shift; }
         // features: relu(LN4(z4)), channels-last [P][128]
         {
             constexpr int ITEMS = G::P * 16, CH = 4;
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const int q = min(q0 + j * THREADS, ITEMS - 1);
-                    z[j] = reinterpret_cast<const bf16x8 *>(zB)[q];
+                    z[j] = reinterpret_cast<const bf16x8 *>(z4)[q];
                     const _Float16 *lq = reinterpret_cast<const _Float16 *>(prm.layer[3].ln) + (size_t)q * 16;
                     l0[j] = *reinterpret_cast<const f16x8 *>(lq);
                     l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
@@ -1164,21 +1176,42 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16 *row_lo, const bf16 *row_hi
     return __builtin_bit_cast(bf16x8, v);
 }
 
-constexpr int WG_THREADS = 512, WG_WAVES = 8, KPAD = 160;
+constexpr int WG_THREADS = 512, WG_WAVES = 8;
+
+// Geometry of one work unit of the weight-gradient kernel: PU pixels of dz (the contraction index, KST k-steps of 32) against
+// the XP pixels of x that their nine taps touch, laid out in a zero-haloed LDS tile of NPOS = 204 positions, PWg per tile row.
+//   WgGeo15:   unit = a sample of the 10 x 15 board: 150 dz pixels, the same 150 x pixels, tile 12 x 17.
+//   WgGeoBand: unit = a band of 4 rows of the 32 x 32 board (8 per sample): 128 dz pixels against the 6 rows (192 pixels) around
+//              them -- contiguous in the channels-last tensors -- tile 6 x 34; rows outside the board are staged as zeros.
+struct WgGeo15 {
+    static constexpr int PU = P, KST = 5, XP = P, PWg = PW;
+    __device__ static __forceinline__ int xpos(int i) { return pos_of(i); }
+    __device__ static __forceinline__ int kpos(int pk) { return pos_of(pk); }
+    __device__ static __forceinline__ long long x_first(int u) { return (long long)u * P; }
+    __device__ static __forceinline__ bool x_valid(int, int) { return true; }
+};
+struct WgGeoBand {
+    static constexpr int PU = 128, KST = 4, XP = 192, PWg = 34;
+    __device__ static __forceinline__ int xpos(int i) { return (i >> 5) * 34 + (i & 31) + 1; }
+    __device__ static __forceinline__ int kpos(int pk) { return ((pk >> 5) + 1) * 34 + (pk & 31) + 1; }
+    __device__ static __forceinline__ long long x_first(int u) { return (long long)u * 128 - 32; }
+    __device__ static __forceinline__ bool x_valid(int u, int i) { return (unsigned)(4 * (u & 7) - 1 + (i >> 5)) < 32u; }
+};
 
 // PF (the wide layers): one block per CU with twice the tiles per wave (MWW = 4: fewer output slices, so x / dz are
 // re-read less often, and fewer LDS reads per MFMA), and the NEXT sample's dz / x chunks are requested into registers
 // before the MFMAs of the current one, so the HBM / L2 latency of the tile fill overlaps the matrix work.
-template <int CINP, int COUT, int MWW, int NBW, bool PF>
+template <int CINP, int COUT, int MWW, int NBW, bool PF, class GEO = WgGeo15>
 __global__ __launch_bounds__(WG_THREADS, PF ? 1 : 2) void k_policy_wgrad(const bf16 *__restrict__ x, const bf16 *__restrict__ dz, float *__restrict__ dw, float *__restrict__ db, int N)
 {
+    constexpr int PU = GEO::PU, KST = GEO::KST, KPADG = 32 * KST, XP = GEO::XP, PWg = GEO::PWg;     // N counts UNITS (GEO)
     constexpr int MSLOTS = WG_WAVES / NBW, MS = MWW * MSLOTS;            // m-blocks (16 channels) per block
     constexpr int MBLOCKS = COUT / 16, Q = (MBLOCKS + MS - 1) / MS;       // output slices (blockIdx.x % Q)
     constexpr int DCH = MS * 16, DSTRIDE = DCH + 8;                      // dz tile: [160][DCH] bf16, 16-B row pad
     constexpr int XSTRIDE = CINP + 8;                                    // x tile:  [204 positions][CINP] bf16, zero halo
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
     bf16 *const dzt = reinterpret_cast<bf16 *>(wg_lds);
-    bf16 *const xt = dzt + KPAD * DSTRIDE;
+    bf16 *const xt = dzt + KPADG * DSTRIDE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
     const int mslot = wave / NBW, nb = wave % NBW;
@@ -1187,7 +1220,7 @@ __global__ __launch_bounds__(WG_THREADS, PF ? 1 : 2) void k_policy_wgrad(const b
     const int mb0 = mslot * MWW;                                         // wave's first m-block inside the slice
     const bool active = co_base + (mb0 + MWW) * 16 <= COUT;              // wave-uniform (layer 1: 2 of 8 m-slots exist)
 
-    for (int i = tid; i < (KPAD * DSTRIDE + NPOS * XSTRIDE) / 8; i += WG_THREADS) {
+    for (int i = tid; i < (KPADG * DSTRIDE + NPOS * XSTRIDE) / 8; i += WG_THREADS) {
         bf16x8 z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
@@ -1203,42 +1236,48 @@ __global__ __launch_bounds__(WG_THREADS, PF ? 1 : 2) void k_policy_wgrad(const b
 
     // per-lane row addresses of the transposing reads: lane 4q + p of group g -> row 8g + 4h + q, columns 4p .. 4p+3
     const int g = lane >> 4, q = (lane >> 2) & 3, p4 = (lane & 3) * 4;
-    int xrow[5][2];
+    int xrow[KST][2];
 #pragma unroll
-    for (int ks = 0; ks < 5; ++ks)
+    for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int pk = 32 * ks + 8 * g + 4 * h + q;                  // pixel of this k row; >= 150: the dz row is zero
-            xrow[ks][h] = (pos_of(min(pk, P - 1)) - (PW + 1)) * XSTRIDE + nb * 16 + p4;
+            xrow[ks][h] = (GEO::kpos(min(pk, PU - 1)) - (PWg + 1)) * XSTRIDE + nb * 16 + p4;
         }
     const int arow = (8 * g + q) * DSTRIDE + mb0 * 16 + p4;
 
     constexpr int DZ_CHUNKS = DCH / 8, X_CHUNKS = CINP / 8;              // 16-byte chunks per pixel row
     static_assert(WG_THREADS % DZ_CHUNKS == 0, "a thread must always load the same channel chunk of dz");
-    constexpr int DZC = (P * DZ_CHUNKS + WG_THREADS - 1) / WG_THREADS, XC = (P * X_CHUNKS + WG_THREADS - 1) / WG_THREADS;
+    constexpr int DZC = (PU * DZ_CHUNKS + WG_THREADS - 1) / WG_THREADS, XC = (XP * X_CHUNKS + WG_THREADS - 1) / WG_THREADS;
     float zsum[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };         // sum over this thread's pixels and samples of its 8 channels of dz
     const int dcols = min(DCH, COUT - co_base);                          // channels of the slice that exist
     const bool dz_mine = (tid % DZ_CHUNKS) * 8 < dcols;                  // this thread's channel chunk exists in the slice
     bf16x8 rdz[DZC], rx[XC];                                             // one sample's chunks of this thread (PF: the next sample's)
 
     auto fetch = [&](int n) {                                            // HBM / L2 -> registers
-        const bf16 *dzn = dz + (size_t)n * P * COUT + co_base, *xn = x + (size_t)n * P * CINP;
+        const bf16 *dzn = dz + (size_t)n * PU * COUT + co_base, *xn = x + GEO::x_first(n) * CINP;
 #pragma unroll
         for (int k = 0; k < DZC; ++k) {
             const int c = tid + k * WG_THREADS, px = c / DZ_CHUNKS, part = c - px * DZ_CHUNKS;
-            if (c < P * DZ_CHUNKS && dz_mine) rdz[k] = *reinterpret_cast<const bf16x8 *>(dzn + (size_t)px * COUT + part * 8);
+            if (c < PU * DZ_CHUNKS && dz_mine) rdz[k] = *reinterpret_cast<const bf16x8 *>(dzn + (size_t)px * COUT + part * 8);
         }
 #pragma unroll
         for (int k = 0; k < XC; ++k) {
             const int c = tid + k * WG_THREADS, px = c / X_CHUNKS, part = c - px * X_CHUNKS;
-            if (c < P * X_CHUNKS) rx[k] = *reinterpret_cast<const bf16x8 *>(xn + (size_t)px * CINP + part * 8);
+            if (c < XP * X_CHUNKS) {
+                if (GEO::x_valid(n, px)) rx[k] = *reinterpret_cast<const bf16x8 *>(xn + (ptrdiff_t)px * CINP + part * 8);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) rx[k][j] = (bf16)0.0f;
+                }
+            }
         }
     };
     auto stage = [&]() {                                                 // registers -> LDS tiles (+ conv bias gradient on the way)
 #pragma unroll
         for (int k = 0; k < DZC; ++k) {
             const int c = tid + k * WG_THREADS, px = c / DZ_CHUNKS, part = c - px * DZ_CHUNKS;
-            if (c < P * DZ_CHUNKS && dz_mine) {
+            if (c < PU * DZ_CHUNKS && dz_mine) {
                 *reinterpret_cast<bf16x8 *>(dzt + px * DSTRIDE + part * 8) = rdz[k];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) zsum[j] += (float)rdz[k][j];
@@ -1247,20 +1286,20 @@ __global__ __launch_bounds__(WG_THREADS, PF ? 1 : 2) void k_policy_wgrad(const b
 #pragma unroll
         for (int k = 0; k < XC; ++k) {
             const int c = tid + k * WG_THREADS, px = c / X_CHUNKS, part = c - px * X_CHUNKS;
-            if (c < P * X_CHUNKS) *reinterpret_cast<bf16x8 *>(xt + pos_of(px) * XSTRIDE + part * 8) = rx[k];
+            if (c < XP * X_CHUNKS) *reinterpret_cast<bf16x8 *>(xt + GEO::xpos(px) * XSTRIDE + part * 8) = rx[k];
         }
     };
     auto mfmas = [&]() {
         if (active) {
 #pragma unroll
-            for (int ks = 0; ks < 5; ++ks) {
+            for (int ks = 0; ks < KST; ++ks) {
                 bf16x8 a[MWW];
 #pragma unroll
                 for (int mi = 0; mi < MWW; ++mi)
                     a[mi] = tr_frag(dzt + arow + (32 * ks) * DSTRIDE + mi * 16, dzt + arow + (32 * ks + 4) * DSTRIDE + mi * 16);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int toff = ((t / 3) * PW + (t % 3)) * XSTRIDE;
+                    const int toff = ((t / 3) * PWg + (t % 3)) * XSTRIDE;
                     const bf16x8 b = tr_frag(xt + xrow[ks][0] + toff, xt + xrow[ks][1] + toff);
 #pragma unroll
                     for (int mi = 0; mi < MWW; ++mi)
@@ -1411,6 +1450,262 @@ __global__ __launch_bounds__(256) void k_obs_to_x0(const void *__restrict__ obs,
     dst[1] = hi;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the BANDED trunk (32 x 32 board, BASELINE config C5 with the fused update).  A sample's layer does not fit
+// LDS (262 KB of bf16 at 128 channels), so the backward runs LAYER BY LAYER over the whole batch, four kinds of kernels per
+// layer, all on the tensors the SAVE forward wrote (z, statistics) and on channels-last bf16 tensors [N][P][C]:
+//   k_band_ln_bwd      one workgroup per sample, two row passes:  dy = da * [x^ w + b > 0],  sums of dx^ = dy w and dx^ x^,
+//                      then dz = rstd (dx^ - mean(dx^) - x^ mean(dx^ x^));  x^ = z rstd + shift is recomputed from the saved z
+//                      with the forward's own expressions, so the ReLU mask is the forward's
+//   k_band_conv_t      da_below = convT(dz) (+ dz for the residual of layer 4): the banded implicit GEMM of the forward
+//                      (band_conv) on the transposed weights, input bands copied raw
+//   k_band_act         a = relu(LN(z)) as a tensor: the x operand of the weight-gradient kernel (the forward never stores it)
+//   k_policy_wgrad<.., WgGeoBand>  weight / bias gradients, one band of 4 rows per work unit
+//   k_band_param_grads LayerNorm weight / bias gradients: per-slice partial sums of dy x^ and dy over the samples
+// HBM-bound passes and MFMA-bound GEMMs alternate as separate launches (no cross-layer fusion: 4.3 GB of activations per
+// 16 384-sample layer cannot stay on chip); what matters here is that C5 TRAINS through kernels of this library at all --
+// the alternative is torch autograd over the f32 module (measured in bench.py extras beside it).
+
+template <int C>
+__global__ __launch_bounds__(THREADS) void k_band_ln_bwd(const bf16 *__restrict__ da, const bf16 *__restrict__ z, const float *__restrict__ stats,
+                                                          int layer, const void *__restrict__ ln_packed, bf16 *__restrict__ dy, bf16 *__restrict__ dz,
+                                                          int pixels, int N)
+{
+    __shared__ float red[2 * WAVES];
+    constexpr int CH = 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int items = pixels * (C / 8);
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        const float rstd = stats[(size_t)n * 8 + 2 * layer], shift = stats[(size_t)n * 8 + 2 * layer + 1];
+        const bf16x8 *da8 = reinterpret_cast<const bf16x8 *>(da + (size_t)n * pixels * C);
+        const bf16x8 *z8 = reinterpret_cast<const bf16x8 *>(z + (size_t)n * pixels * C);
+        bf16x8 *dy8 = reinterpret_cast<bf16x8 *>(dy + (size_t)n * pixels * C), *dz8 = reinterpret_cast<bf16x8 *>(dz + (size_t)n * pixels * C);
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 1
+        for (int q0 = tid; q0 < items; q0 += CH * THREADS) {                 // pass A
+            bf16x8 a[CH], zz[CH];
+            f16x8 l0[CH], l1[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int q = min(q0 + j * THREADS, items - 1);
+                a[j] = da8[q]; zz[j] = z8[q];
+                const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;
+                l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+                l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+            }
+            POL_PIN();
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int q = q0 + j * THREADS;
+                if (q < items) {
+                    bf16x8 d;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float g = (float)(e < 4 ? l0[j][e] : l1[j][e - 4]), bb = (float)(e < 4 ? l0[j][4 + e] : l1[j][e]);
+                        const float xh = fmaf((float)zz[j][e], rstd, shift);
+                        const bool on = fmaf(xh, g, bb) > 0.0f;                 // ln_relu8's expression: the forward's mask
+                        d[e] = on ? a[j][e] : (bf16)0.0f;
+                        const float dxh = (float)d[e] * g;
+                        s1 += dxh;
+                        s2 = fmaf(dxh, xh, s2);
+                    }
+                    dy8[q] = d;
+                }
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { red[wave] = s1; red[WAVES + wave] = s2; }
+        __syncthreads();
+        float S1 = 0.0f, S2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { S1 += red[w]; S2 += red[WAVES + w]; }
+        const float inv_cnt = 1.0f / ((float)C * (float)pixels);
+        const float m1 = S1 * inv_cnt, m2 = S2 * inv_cnt;
+#pragma unroll 1
+        for (int q0 = tid; q0 < items; q0 += CH * THREADS) {                 // pass B: the same items, this thread's own dy
+            bf16x8 d[CH], zz[CH];
+            f16x8 l0[CH], l1[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int q = min(q0 + j * THREADS, items - 1);
+                d[j] = dy8[q]; zz[j] = z8[q];
+                const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;
+                l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+                l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+            }
+            POL_PIN();
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int q = q0 + j * THREADS;
+                if (q < items) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float g = (float)(e < 4 ? l0[j][e] : l1[j][e - 4]);
+                        const float xh = fmaf((float)zz[j][e], rstd, shift);
+                        o[e] = (bf16)(rstd * ((float)d[j][e] * g - m1 - xh * m2));
+                    }
+                    dz8[q] = o;
+                }
+            }
+        }
+        __syncthreads();                                                     // red[] is rewritten by the next sample
+    }
+}
+
+// raw band loader: tile <- the band's R + 2 rows of a channels-last tensor [P][CSRC], zeros outside the board
+template <class G, int R, int CSRC>
+__device__ __forceinline__ void band_load_raw(bf16 *tile, const bf16 *__restrict__ src, int band)
+{
+    constexpr int C8 = CSRC / 8, ITEMS = G::TR * G::PWB * C8, NIT = (ITEMS + THREADS - 1) / THREADS, CH = NIT < 8 ? NIT : 8;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma unroll 1
+    for (int k0 = 0; k0 < NIT; k0 += CH) {
+        bf16x8 v[CH];
+        int dsto[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int q = tid + (k0 + j) * THREADS;
+            const int pos = q / C8, part = q - pos * C8, tr = pos / G::PWB, tc = pos - tr * G::PWB;
+            const int y = band * R + tr - 1, x = tc - 1;
+            const bool in = q < ITEMS && (unsigned)y < (unsigned)(G::P / (G::PWB - 2)) && (unsigned)x < (unsigned)(G::PWB - 2);
+            dsto[j] = q < ITEMS ? pos * CSF + part * 8 : -1;
+            const int p = in ? y * (G::PWB - 2) + x : 0;
+            v[j] = *reinterpret_cast<const bf16x8 *>(src + (size_t)p * CSRC + part * 8);
+            if (!in) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = (bf16)0.0f;
+            }
+        }
+        POL_PIN();
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (dsto[j] >= 0) *reinterpret_cast<bf16x8 *>(tile + dsto[j]) = v[j];
+    }
+}
+
+// da_below[n] = convT(dz[n]) (+ dz[n]: RESIDUAL, the skip connection around conv4).  lp.w: the transposed packing of the layer's
+// weights (inv_policy_pack_conv(transposed = 1)), lp.bias: zeros.
+template <int HB, int WB, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL, bool SPLIT>
+__global__ __launch_bounds__(THREADS, 2) void k_band_conv_t(inv_policy_layer lp, const bf16 *__restrict__ dz, bf16 *__restrict__ da_out, int N)
+{
+    using G = BandGeo<HB, WB, R>;
+    __shared__ __attribute__((aligned(16))) bf16 tile[G::NPOSB * CSF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
+    for (int i = tid; i < G::NPOSB * CSF / 8; i += THREADS) {
+        bf16x8 zz;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zz[j] = (bf16)0.0f;
+        reinterpret_cast<bf16x8 *>(&tile[0])[i] = zz;
+    }
+    __syncthreads();
+    // SPLIT (COUT = 32): two row blocks x two halves of the band's tiles over the four waves, like layer 1 of the forward
+    const int m0 = SPLIT ? (wave & 1) : wave * MW, n0 = SPLIT ? (wave >> 1) * NW : 0;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        int lane_i = lane;
+        asm volatile("" : "+v"(lane_i));
+        const bf16 *src = dz + (size_t)n * G::P * CIN;
+        bf16 *dst = da_out + (size_t)n * G::P * COUT;
+        float s = 0.0f, ss = 0.0f;                                          // band_conv's statistics: unused here
+#pragma unroll 1
+        for (int band = 0; band < G::NB; ++band) {
+            band_load_raw<G, R, CIN>(tile, src, band);
+            __syncthreads();
+            band_conv<G, R, CIN, COUT, MW, NW, RESIDUAL>(lp, tile, dst, band, lane_i, m0, n0, s, ss);
+        }
+    }
+}
+
+// a = relu(LN(z)) for a whole tensor [N][P][C] (the forward applies it on the fly while it builds a band; the weight-gradient
+// kernel wants it as its x operand)
+template <int C>
+__global__ __launch_bounds__(THREADS) void k_band_act(const bf16 *__restrict__ z, const float *__restrict__ stats, int layer,
+                                                       const void *__restrict__ ln_packed, bf16 *__restrict__ act, int pixels, long long total_items)
+{
+    constexpr int CH = 4;
+    const int items = pixels * (C / 8);
+    for (long long g0 = (long long)blockIdx.x * THREADS * CH + threadIdx.x; g0 < total_items; g0 += (long long)gridDim.x * THREADS * CH) {
+        bf16x8 zz[CH];
+        f16x8 l0[CH], l1[CH];
+        float rs[CH], sh[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const long long g = min(g0 + (long long)j * THREADS, total_items - 1);
+            const long long n = g / items;
+            const int q = (int)(g - n * items);
+            zz[j] = reinterpret_cast<const bf16x8 *>(z)[g];
+            const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;
+            l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+            l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+            rs[j] = stats[n * 8 + 2 * layer]; sh[j] = stats[n * 8 + 2 * layer + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const long long g = g0 + (long long)j * THREADS;
+            if (g < total_items) reinterpret_cast<bf16x8 *>(act)[g] = ln_relu8(zz[j], l0[j], l1[j], rs[j], sh[j]);
+        }
+    }
+}
+
+// LayerNorm weight / bias gradients of a banded layer: like k_policy_param_grads, with x^ = z rstd + shift recomputed from the
+// saved z and the per-sample statistics
+__global__ __launch_bounds__(256) void k_band_param_grads(const bf16 *__restrict__ dy, const bf16 *__restrict__ z, const float *__restrict__ stats,
+                                                           int layer, float *__restrict__ part, int E8, int N)
+{
+    const int e8 = blockIdx.x * 256 + threadIdx.x;
+    if (e8 >= E8) return;
+    float aw[8], ab[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aw[j] = ab[j] = 0.0f;
+    const size_t stride = (size_t)E8 * 8;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const size_t o = (size_t)n * stride + (size_t)e8 * 8;
+        const bf16x8 d = *reinterpret_cast<const bf16x8 *>(dy + o);
+        const bf16x8 zz = *reinterpret_cast<const bf16x8 *>(z + o);
+        const float rstd = stats[(size_t)n * 8 + 2 * layer], shift = stats[(size_t)n * 8 + 2 * layer + 1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float df = (float)d[j];
+            aw[j] = fmaf(df, fmaf((float)zz[j], rstd, shift), aw[j]);
+            ab[j] += df;
+        }
+    }
+    float *o = part + (size_t)blockIdx.y * 2 * stride + (size_t)e8 * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(aw[0], aw[1], aw[2], aw[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(aw[4], aw[5], aw[6], aw[7]);
+    *reinterpret_cast<float4 *>(o + stride) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+    *reinterpret_cast<float4 *>(o + stride + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
+}
+
+// obs_to_x0 for any board: bf16 channels-last [N][pixels][16] from f32 planes [N][12][pixels] or packed bitstrings [N][ceil(12 pixels / 32)]
+__global__ __launch_bounds__(256) void k_obs_to_x0_any(const void *__restrict__ obs, int is_bits, bf16 *__restrict__ x0, int pixels, int N)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;      // one (sample, pixel)
+    if (e >= (long long)N * pixels) return;
+    const int n = (int)(e / pixels), p = (int)(e - (long long)n * pixels);
+    const int words = (12 * pixels + 31) / 32;
+    bf16x8 lo, hi;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float v = 0.0f;
+        if (c < 12) {
+            if (is_bits) {
+                const int bit = c * pixels + p;
+                v = (float)((reinterpret_cast<const uint32_t *>(obs)[(size_t)n * words + (bit >> 5)] >> (bit & 31)) & 1u);
+            } else {
+                v = reinterpret_cast<const float *>(obs)[((size_t)n * 12 + c) * pixels + p];
+            }
+        }
+        if (c < 8) lo[c] = (bf16)v; else hi[c - 8] = (bf16)v;
+    }
+    bf16x8 *dst = reinterpret_cast<bf16x8 *>(x0 + (size_t)e * 16);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
 }  // namespace pol
 
 #ifdef INV_POLICY_STAMPS
@@ -1512,13 +1807,115 @@ extern "C" int inv_policy_trunk_banded(const inv_policy_params *params, const vo
     if (scratch_bytes < inv_policy_trunk_banded_scratch_bytes(height, width)) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_banded: scratch too small");
     if (N == 0) return INV_OK;
     const int grid = trunk_grid(N);
+    inv_policy_band_saved none;
+    memset(&none, 0, sizeof none);
     if (obs_is_bits)
         hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
-                           reinterpret_cast<pol::bf16 *>(feat_bf16), reinterpret_cast<pol::bf16 *>(scratch), (int)N);
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), reinterpret_cast<pol::bf16 *>(scratch), (int)N, none);
     else
         hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
-                           reinterpret_cast<pol::bf16 *>(feat_bf16), reinterpret_cast<pol::bf16 *>(scratch), (int)N);
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), reinterpret_cast<pol::bf16 *>(scratch), (int)N, none);
     return launch_status("inv_policy_trunk_banded");
+}
+
+// ---- BASELINE config C5 with the fused update: training forward and the layer-by-layer backward of the banded trunk (32 x 32)
+static bool band_dims_ok(int32_t height, int32_t width) { return height == 32 && width == 32; }
+static const int kBandC[4] = { 32, 64, 128, 128 };
+
+extern "C" int inv_policy_trunk_banded_train_fwd(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, int32_t height, int32_t width,
+                                                 void *feat_bf16, const inv_policy_band_saved *saved, int32_t N, void *stream)
+{
+    if (!params || !obs || !feat_bf16 || !saved || N < 0 || !layers_ok(params) || !saved->stats || !saved->z[0] || !saved->z[1] || !saved->z[2] || !saved->z[3])
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_banded_train_fwd: NULL params / obs / feat / saved tensor, or N < 0");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_trunk_banded_train_fwd: built for the 32 x 32 board (got %d x %d)", (int)width, (int)height);
+    if (N == 0) return INV_OK;
+    const int grid = trunk_grid(N);
+    if (obs_is_bits)
+        hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, true, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (pol::bf16 *)nullptr, (int)N, *saved);
+    else
+        hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, false, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+                           reinterpret_cast<pol::bf16 *>(feat_bf16), (pol::bf16 *)nullptr, (int)N, *saved);
+    return launch_status("inv_policy_trunk_banded_train_fwd");
+}
+
+extern "C" int inv_policy_band_ln_bwd(int32_t layer, int32_t height, int32_t width, const void *da_bf16, const void *z_bf16, const float *stats,
+                                      const void *ln_packed, void *dy_bf16, void *dz_bf16, int32_t N, void *stream)
+{
+    if (!da_bf16 || !z_bf16 || !stats || !ln_packed || !dy_bf16 || !dz_bf16 || N < 0 || layer < 0 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_ln_bwd: NULL tensor, N < 0 or layer outside 0..3");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_ln_bwd: built for the 32 x 32 board");
+    if (N == 0) return INV_OK;
+    const int pixels = height * width, grid = N < 4 * inv_cu_count() ? N : 4 * inv_cu_count();
+    using pol::bf16;
+#define INV_LNB(C_) hipLaunchKernelGGL((pol::k_band_ln_bwd<C_>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, reinterpret_cast<const bf16 *>(da_bf16), \
+        reinterpret_cast<const bf16 *>(z_bf16), stats, (int)layer, ln_packed, reinterpret_cast<bf16 *>(dy_bf16), reinterpret_cast<bf16 *>(dz_bf16), pixels, (int)N)
+    if (kBandC[layer] == 32) INV_LNB(32); else if (kBandC[layer] == 64) INV_LNB(64); else INV_LNB(128);
+#undef INV_LNB
+    return launch_status("inv_policy_band_ln_bwd");
+}
+
+extern "C" int inv_policy_band_conv_t(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,
+                                      const void *dz_bf16, void *da_below_bf16, int32_t N, void *stream)
+{
+    if (!wt_packed || !zero_bias || !dz_bf16 || !da_below_bf16 || N < 0 || layer < 1 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_conv_t: NULL tensor, N < 0 or layer outside 1..3 (layer 0 has no data gradient)");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_conv_t: built for the 32 x 32 board");
+    if (N == 0) return INV_OK;
+    const int grid = trunk_grid(N);
+    inv_policy_layer lp;
+    lp.w = wt_packed; lp.bias = zero_bias; lp.ln = nullptr;
+    using pol::bf16;
+    using G = pol::BandGeo<32, 32, 4>;
+    const bf16 *src = reinterpret_cast<const bf16 *>(dz_bf16);
+    bf16 *dst = reinterpret_cast<bf16 *>(da_below_bf16);
+    if (layer == 3)        // dz4 [128] -> da3 [128], + dz4 (residual)
+        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 128, 128, 2, G::NT, true, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N);
+    else if (layer == 2)   // dz3 [128] -> da2 [64]
+        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 128, 64, 1, G::NT, false, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N);
+    else                   // dz2 [64] -> da1 [32]
+        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 64, 32, 1, G::NT / 2, false, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N);
+    return launch_status("inv_policy_band_conv_t");
+}
+
+extern "C" int inv_policy_band_act(int32_t layer, int32_t height, int32_t width, const void *z_bf16, const float *stats, const void *ln_packed,
+                                   void *act_bf16, int32_t N, void *stream)
+{
+    if (!z_bf16 || !stats || !ln_packed || !act_bf16 || N < 0 || layer < 0 || layer > 2)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_act: NULL tensor, N < 0 or layer outside 0..2");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_act: built for the 32 x 32 board");
+    if (N == 0) return INV_OK;
+    const int pixels = height * width, C_ = kBandC[layer];
+    const long long total = (long long)N * pixels * (C_ / 8);
+    long long blocks = (total + pol::THREADS * 4 - 1) / (pol::THREADS * 4);
+    if (blocks > 16 * (long long)inv_cu_count()) blocks = 16 * (long long)inv_cu_count();
+    using pol::bf16;
+#define INV_ACT(C__) hipLaunchKernelGGL((pol::k_band_act<C__>), dim3((unsigned)blocks), dim3(pol::THREADS), 0, (hipStream_t)stream, reinterpret_cast<const bf16 *>(z_bf16), \
+        stats, (int)layer, ln_packed, reinterpret_cast<bf16 *>(act_bf16), pixels, total)
+    if (C_ == 32) INV_ACT(32); else if (C_ == 64) INV_ACT(64); else INV_ACT(128);
+#undef INV_ACT
+    return launch_status("inv_policy_band_act");
+}
+
+extern "C" int inv_policy_band_param_grads(int32_t layer, const void *dy_bf16, const void *z_bf16, const float *stats, float *partial, int32_t slices,
+                                           int32_t elems_per_sample, int32_t N, void *stream)
+{
+    if (!dy_bf16 || !z_bf16 || !stats || !partial || N < 0 || slices < 1 || elems_per_sample <= 0 || (elems_per_sample & 7) || layer < 0 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_param_grads: NULL tensor, N < 0, slices < 1, layer outside 0..3 or elems_per_sample not a positive multiple of 8");
+    const int e8 = elems_per_sample / 8, bx = (e8 + 255) / 256;
+    hipLaunchKernelGGL(pol::k_band_param_grads, dim3(bx, slices), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const pol::bf16 *>(dy_bf16),
+                       reinterpret_cast<const pol::bf16 *>(z_bf16), stats, (int)layer, partial, e8, (int)N);
+    return launch_status("inv_policy_band_param_grads");
+}
+
+extern "C" int inv_policy_obs_to_x0_any(const void *obs, int32_t obs_is_bits, int32_t pixels, void *x0_bf16, int32_t N, void *stream)
+{
+    if (!obs || !x0_bf16 || N < 0 || pixels < 1) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_obs_to_x0_any: NULL tensor, N < 0 or pixels < 1");
+    if (N == 0) return INV_OK;
+    const long long total = (long long)N * pixels;
+    hipLaunchKernelGGL(pol::k_obs_to_x0_any, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, (int)(obs_is_bits != 0),
+                       reinterpret_cast<pol::bf16 *>(x0_bf16), (int)pixels, (int)N);
+    return launch_status("inv_policy_obs_to_x0_any");
 }
 
 extern "C" int inv_policy_trunk(const inv_policy_params *params, const float *obs, void *feat_bf16, int32_t N, void *stream)
@@ -1583,17 +1980,17 @@ extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const i
     return launch_status("inv_policy_trunk_bwd");
 }
 
-template <int CINP, int COUT, int MWW, int NBW, bool PF>
+template <int CINP, int COUT, int MWW, int NBW, bool PF, class GEO = pol::WgGeo15>
 static int launch_wgrad(const void *x, const void *dz, float *dw, float *db, int N, hipStream_t st)
 {
     constexpr int MS = MWW * (pol::WG_WAVES / NBW), Q = (COUT / 16 + MS - 1) / MS;
     constexpr int DSTRIDE = MS * 16 + 8, XSTRIDE = CINP + 8;
-    constexpr size_t lds = (size_t)(pol::KPAD * DSTRIDE + pol::NPOS * XSTRIDE) * 2;
+    constexpr size_t lds = (size_t)(32 * GEO::KST * DSTRIDE + pol::NPOS * XSTRIDE) * 2;
     static bool attr_set[64] = { false };            // per device ordinal: the attribute belongs to the device's code object
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF, GEO>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "inv_policy_wgrad: hipFuncSetAttribute(%d B of LDS): %s", (int)lds, hipGetErrorString(e));
         attr_set[dev] = true;
@@ -1601,7 +1998,7 @@ static int launch_wgrad(const void *x, const void *dz, float *dw, float *db, int
     const int blocks = PF ? trunk_grid(N) / 2 : trunk_grid(N);          // PF: one 8-wave block per CU; else two (<= 126 VGPRs, <= 68 KB LDS)
     const int per_slice = blocks / Q > 0 ? blocks / Q : 1;
     const int nslices = N < per_slice ? N : per_slice;
-    hipLaunchKernelGGL((pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF>), dim3(nslices * Q), dim3(pol::WG_THREADS), lds, st,
+    hipLaunchKernelGGL((pol::k_policy_wgrad<CINP, COUT, MWW, NBW, PF, GEO>), dim3(nslices * Q), dim3(pol::WG_THREADS), lds, st,
                        reinterpret_cast<const pol::bf16 *>(x), reinterpret_cast<const pol::bf16 *>(dz), dw, db, N);
     return launch_status("inv_policy_wgrad");
 }
@@ -1623,6 +2020,25 @@ extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *d
     case 1: return launch_wgrad<POL_WG1>(x_bf16, dz_bf16, dw, dbias, N, st);
     case 2: return launch_wgrad<64, 128, 4, 4, true>(x_bf16, dz_bf16, dw, dbias, N, st);
     default: return launch_wgrad<128, 128, 4, 8, true>(x_bf16, dz_bf16, dw, dbias, N, st);
+    }
+}
+
+// weight / bias gradients of the banded trunk: N samples of the 32 x 32 board = 8 N band units of 128 dz pixels (WgGeoBand)
+extern "C" int inv_policy_band_wgrad(int32_t layer, int32_t height, int32_t width, const void *x_bf16, const void *dz_bf16, float *dw, float *dbias,
+                                     int32_t N, void *stream)
+{
+    if (!x_bf16 || !dz_bf16 || !dw || N < 0 || layer < 0 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_wgrad: NULL x / dz / dw, N < 0 or layer outside 0..3 (dbias may be NULL)");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_wgrad: built for the 32 x 32 board");
+    if (N == 0) return INV_OK;
+    if ((long long)N * 8 > 0x7fffffffLL) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_wgrad: N too large");
+    hipStream_t st = (hipStream_t)stream;
+    const int units = N * 8;
+    switch (layer) {
+    case 0: return launch_wgrad<16, 32, 1, 1, false, pol::WgGeoBand>(x_bf16, dz_bf16, dw, dbias, units, st);
+    case 1: return launch_wgrad<32, 64, 1, 2, true, pol::WgGeoBand>(x_bf16, dz_bf16, dw, dbias, units, st);
+    case 2: return launch_wgrad<64, 128, 4, 4, true, pol::WgGeoBand>(x_bf16, dz_bf16, dw, dbias, units, st);
+    default: return launch_wgrad<128, 128, 4, 8, true, pol::WgGeoBand>(x_bf16, dz_bf16, dw, dbias, units, st);
     }
 }
 

@@ -86,8 +86,8 @@ class FusedPolicy:
         self.P = self.H * self.W
         self.OW = (12 * self.P + 31) // 32
         self.banded = (self.H, self.W) != (10, 15)
-        if self.banded and self.train_numerics:
-            raise ValueError("the fused update (and its rollout numerics) exists for the 15 x 10 board only")
+        # (banded boards: the training forward IS the inference kernel with other destinations for its intermediates, so
+        # train_numerics changes nothing there -- the rollout's features are the update's bit for bit either way)
         if self.banded:
             with torch.cuda.device(dev):                                 # the size depends on the CU count of THIS device
                 self._scratch_bytes = int(self.lib.inv_policy_trunk_banded_scratch_bytes(self.H, self.W))
@@ -153,7 +153,7 @@ class FusedPolicy:
                 rc = self.lib.inv_policy_trunk_banded(C.byref(self.params), C.c_void_p(grid.data_ptr()), int(bits), self.H, self.W,
                                                       C.c_void_p(feat.data_ptr()), C.c_void_p(scratch.data_ptr()), scratch.numel(),
                                                       grid.shape[0], st)
-            elif self.train_numerics:
+            elif self.train_numerics:                                  # 15 x 10 only
                 rc = self.lib.inv_policy_trunk_train_fwd(C.byref(self.params), C.c_void_p(grid.data_ptr()), int(bits),
                                                          C.c_void_p(feat.data_ptr()), None, grid.shape[0], st)
             else:

@@ -189,6 +189,91 @@ class _TrunkTrainFn(torch.autograd.Function):
         return tuple(out)
 
 
+class _TrunkTrainBandedFn(torch.autograd.Function):
+    """features = trunk(obs; ...) for boards whose layers do not fit LDS (32 x 32, BASELINE config C5): the banded forward keeps
+    the layers' pre-norm outputs z and the LayerNorm statistics; the backward runs layer by layer over the whole batch
+    (csrc/inv_policy.hip: k_band_ln_bwd, k_band_conv_t, k_band_act, k_policy_wgrad<.., WgGeoBand>, k_band_param_grads).
+    Reference: autograd over policies.py:91-99 at H = W = 32."""
+
+    @staticmethod
+    def forward(ctx, obs, *params):
+        lib = L.load()
+        dev, n = obs.device, obs.shape[0]
+        bits = obs.dtype == torch.int32
+        obs = obs.contiguous() if bits else obs.contiguous().float()
+        cout0, hb, wb = (int(v) for v in params[2].shape)                          # LayerNorm([C, H, W]) weight of layer 1
+        pix = hb * wb
+        keep, fwd, lns = [], L.InvPolicyParams(), []
+        for i in range(4):
+            w, b, g, e = params[4 * i:4 * i + 4]
+            wp = pack_conv(w, _CIN_PAD[i])
+            bp = b.detach().float().contiguous()
+            ln = pack_ln(g, e, _COUT[i])
+            keep += [wp, bp, ln]
+            lns.append(ln)
+            fwd.layer[i] = L.InvPolicyLayer(wp.data_ptr(), bp.data_ptr(), ln.data_ptr())
+        z = [torch.empty((n, pix, c), dtype=torch.bfloat16, device=dev) for c in _COUT]
+        stats = torch.empty((n, 4, 2), dtype=torch.float32, device=dev)
+        feat = torch.empty((n, pix * 128), dtype=torch.bfloat16, device=dev)
+        saved = L.InvPolicyBandSaved()
+        for i in range(4):
+            saved.z[i] = z[i].data_ptr()
+        saved.stats = stats.data_ptr()
+        with torch.cuda.device(dev):
+            rc = lib.inv_policy_trunk_banded_train_fwd(C.byref(fwd), _ptr(obs), 1 if bits else 0, hb, wb, _ptr(feat), C.byref(saved), n,
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.raise_for(rc, lib)
+        ctx.save_for_backward(obs, stats, *z, *lns, *[params[4 * i] for i in range(4)])
+        ctx.bits, ctx.hw = bits, (hb, wb)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = L.load()
+        sv = ctx.saved_tensors
+        obs, stats = sv[0], sv[1]
+        z, lns, ws = sv[2:6], sv[6:10], sv[10:14]
+        dev, n = obs.device, obs.shape[0]
+        hb, wb = ctx.hw
+        pix = hb * wb
+        zero_bias = torch.zeros(128, dtype=torch.float32, device=dev)
+        da = dfeat.contiguous().to(torch.bfloat16)
+        grads = [None] * 16
+
+        def st():
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        with torch.cuda.device(dev):
+            for l in (3, 2, 1, 0):
+                c = _COUT[l]
+                dy, dz = torch.empty_like(z[l]), torch.empty_like(z[l])
+                L.raise_for(lib.inv_policy_band_ln_bwd(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(dy), _ptr(dz), n, st()), lib)
+                slices = max(1, min(n, _RED_SLICES))
+                part = torch.empty((slices, 2, pix, c), dtype=torch.float32, device=dev)
+                L.raise_for(lib.inv_policy_band_param_grads(l, _ptr(dy), _ptr(z[l]), _ptr(stats), _ptr(part), slices, pix * c, n, st()), lib)
+                red = part.sum(dim=0)
+                grads[4 * l + 2], grads[4 * l + 3] = red[0].t().reshape(c, hb, wb), red[1].t().reshape(c, hb, wb)
+                del dy, part
+                da = None
+                if l >= 1:
+                    wt = pack_conv(ws[l], _COUT[l], transposed=True)
+                    da = torch.empty((n, pix, _COUT[l - 1]), dtype=torch.bfloat16, device=dev)
+                    L.raise_for(lib.inv_policy_band_conv_t(l, hb, wb, _ptr(wt), _ptr(zero_bias), _ptr(dz), _ptr(da), n, st()), lib)
+                    x = torch.empty((n, pix, _COUT[l - 1]), dtype=torch.bfloat16, device=dev)
+                    L.raise_for(lib.inv_policy_band_act(l - 1, hb, wb, _ptr(z[l - 1]), _ptr(stats), _ptr(lns[l - 1]), _ptr(x), n, st()), lib)
+                else:
+                    x = torch.empty((n, pix, 16), dtype=torch.bfloat16, device=dev)
+                    L.raise_for(lib.inv_policy_obs_to_x0_any(_ptr(obs), 1 if ctx.bits else 0, pix, _ptr(x), n, st()), lib)
+                cin, cinp = _CIN[l], _CINP[l]
+                dw = torch.zeros((c, 9, cinp), dtype=torch.float32, device=dev)
+                db = torch.zeros((c,), dtype=torch.float32, device=dev)
+                L.raise_for(lib.inv_policy_band_wgrad(l, hb, wb, _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), n, st()), lib)
+                grads[4 * l] = dw[:, :, :cin].reshape(c, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+                grads[4 * l + 1] = db
+                del dz, x
+        return (None, *grads)
+
+
 class _DirectCtx:
     """Stand-in for the autograd context when a Function's forward / backward are called directly (loss_and_grads)."""
     needs_input_grad = (True,) * 32
@@ -214,15 +299,19 @@ class FusedTrainPolicy:
 
     def __init__(self, policy):
         p = policy
-        if tuple(p.norm1.normalized_shape) != (32, 10, 15) or p.conv1.in_channels != 12:
-            raise ValueError("the fused trunk supports the reference's 12 x 10 x 15 observation only")
+        shape = tuple(p.norm1.normalized_shape)
+        if shape not in ((32, 10, 15), (32, 32, 32)) or p.conv1.in_channels != 12:
+            raise ValueError("the fused trunk trains 12-channel observations of the 15 x 10 and 32 x 32 boards only")
         if p.conv1.weight.device.type != "cuda":
             raise RuntimeError("FusedTrainPolicy needs the policy on the GPU")
         self.policy = policy
+        # 15 x 10: one fused forward kernel + one fused backward kernel, activations in LDS; 32 x 32: the banded forward and a
+        # layer-by-layer backward over the whole batch
+        self.trunk_fn = _TrunkTrainFn if shape == (32, 10, 15) else _TrunkTrainBandedFn
         L.load()
 
     def features(self, grid):
-        return _TrunkTrainFn.apply(grid, *_trunk_params(self.policy))
+        return self.trunk_fn.apply(grid, *_trunk_params(self.policy))
 
     @torch.no_grad()
     def loss_and_grads(self, grid, extra, actions, old_log_probs, advantages, returns, clip_ratio, value_coef, entropy_coef,
@@ -240,7 +329,7 @@ class FusedTrainPolicy:
         if any(q.grad is None for q in tparams + hparams):
             raise RuntimeError("loss_and_grads writes into existing .grad tensors (FlatAdam / FlatGradReducer create them)")
         tctx, hctx, lctx = _DirectCtx(), _DirectCtx(), _DirectCtx()
-        feat = _TrunkTrainFn.forward(tctx, grid, *tparams)
+        feat = self.trunk_fn.forward(tctx, grid, *tparams)
         logits, value = HD._HeadsTrainFn.forward(hctx, feat, extra, *hparams)
         if actions.dtype != torch.int64:
             actions = actions.to(torch.int64)
@@ -255,7 +344,7 @@ class FusedTrainPolicy:
         torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
         if after_heads is not None:
             after_heads()
-        tg = _TrunkTrainFn.backward(tctx, hg[0])
+        tg = self.trunk_fn.backward(tctx, hg[0])
         torch._foreach_copy_([q.grad for q in tparams], list(tg[1:]))
         return means
 
@@ -265,13 +354,14 @@ class FusedTrainPolicy:
         if HD.supported(p):
             return HD.heads_train(p, feat, extra)                                      # fused heads (csrc/inv_heads.hip)
         extra = extra.float()
-        # first Linear of both heads as ONE [512 x 19200] bf16 GEMM on the kernel's feature order (columns permuted from
-        # the module's c*150 + pixel to pixel*128 + c); autograd splits the gradient back onto the two weight tensors
-        w = torch.cat([p.fc_actor[0].weight, p.fc_critic[0].weight])                    # [512, 19204]
+        # first Linear of both heads as ONE [512 x 128 P] bf16 GEMM on the kernel's feature order (columns permuted from
+        # the module's c*P + pixel to pixel*128 + c); autograd splits the gradient back onto the two weight tensors
+        w = torch.cat([p.fc_actor[0].weight, p.fc_critic[0].weight])                    # [512, 128 P + 4]
         b = torch.cat([p.fc_actor[0].bias, p.fc_critic[0].bias])
         hid = p.fc_actor[0].out_features
-        wf = w[:, :19200].reshape(-1, 128, 150).permute(0, 2, 1).reshape(-1, 19200).to(torch.bfloat16)
-        h = torch.relu((feat @ wf.t()).float() + extra @ w[:, 19200:].t() + b)
+        nf = feat.shape[1]
+        wf = w[:, :nf].reshape(-1, 128, nf // 128).permute(0, 2, 1).reshape(-1, nf).to(torch.bfloat16)
+        h = torch.relu((feat @ wf.t()).float() + extra @ w[:, nf:].t() + b)
         logits = p.fc_actor[4](torch.relu(p.fc_actor[2](h[:, :hid])))
         value = p.fc_critic[4](torch.relu(p.fc_critic[2](h[:, hid:])))
         return logits, value

@@ -52,14 +52,17 @@ def test_banded_trunk_matches_the_f32_module(n):
     assert float((logits - lw).abs().max()) < 0.05 and float((value - vw).abs().max()) < 0.05
 
 
-def test_banded_trunk_rejects_other_boards_and_the_fused_update():
+def test_banded_trunk_rejects_other_boards():
     import torch
     from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.fused_train import FusedTrainPolicy
     from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
     with pytest.raises(ValueError):
         FusedPolicy(InversusCNNPolicy(12, 16, 16, 4).cuda())
     with pytest.raises(ValueError):
-        FusedPolicy(InversusCNNPolicy(12, 32, 32, 4).cuda(), train_numerics=True)
+        FusedTrainPolicy(InversusCNNPolicy(12, 16, 16, 4).cuda())
+    # round 3: the 32 x 32 board has a fused update too (tests/test_gpu_fused_train_32x32.py); train_numerics is a no-op there
+    assert FusedPolicy(InversusCNNPolicy(12, 32, 32, 4).cuda(), train_numerics=True).banded
     fused = FusedPolicy(make_policy(torch))
     with pytest.raises(ValueError):
         fused.features(torch.zeros(4, 12, 10, 15, device="cuda"))
