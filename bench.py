@@ -371,6 +371,32 @@ def side_measurements(torch, np, n):
         res["train_env_steps_per_s_4_epochs"] = round(T * n / ((t1 - t0) + (t4 - t3)))
         return res
     guard("PPO iteration (selfplay, packed obs, fused act + fused update, minibatch = 16384; 1 epoch and the reference's 4 epochs)", update_cfg)
+
+    def c5_update_cfg():
+        """BASELINE config C5 trained through the fused path (round 3): self-play collection on the 32 x 32 board and the PPO update
+        through the banded training kernels, minibatch = 16 384; medians of 3 iterations.  The reference-shaped alternative --
+        torch autograd over the f32 module -- costs ~390 ms per such minibatch (tools/c5_update_speed.py, profiles/)."""
+        from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+        from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+        from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+        from inversus_reinforcement_learning_amd.training import RolloutCollector
+        torch.manual_seed(0)
+        b = DeviceEnvBatch(n, 32, 32, K, opponent="selfplay")
+        b.seed(np.arange(n, dtype=np.int64)); b.reset()
+        agent = PPOAgent(InversusCNNPolicy(12, 32, 32, 4), fused_act=True, fused_update=True, batch_size=n, epochs=1)
+        col = RolloutCollector(b, agent, FusedPolicy(InversusCNNPolicy(12, 32, 32, 4).cuda().eval(), actor_only=True))
+        T = 2
+        col.collect(T); agent.update(); torch.cuda.synchronize()
+        cs, us = [], []
+        for _ in range(3):
+            t0 = time.perf_counter(); col.collect(T); torch.cuda.synchronize(); t1 = time.perf_counter()
+            agent.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
+            cs.append(t1 - t0); us.append(t2 - t1)
+        c, u = sorted(cs)[1], sorted(us)[1]
+        return {"rollout_steps": T, "minibatch": n, "collect_ms_per_vector_step": round(c * 1e3 / T, 2),
+                "selfplay_collector_env_steps_per_s": round(n * T / c), "fused_update_ms_per_minibatch": round(u * 1e3 / T, 2),
+                "train_env_steps_per_s_1_epoch": round(n * T / (c + u)), "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
+    guard("C5 PPO iteration: 32x32 self-play collection + fused (banded) update, minibatch = 16384", c5_update_cfg)
     return out
 
 
