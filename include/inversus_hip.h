@@ -281,6 +281,15 @@ int  inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const inv_policy_
  * (layer 0: the 12 observation planes padded with 4 zero channels); dz: what inv_policy_trunk_bwd wrote.
  * MFMA over pixels through transposing LDS reads. */
 int  inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *dz_bf16, float *dw, float *dbias, int32_t N, void *stream);
+/* The four layers' dw blocks ([Cout][9][CinP], back to back in `src`: 32x9x16, 64x9x32, 128x9x64, 128x9x128 floats) -> the module's
+ * tensors dw[l] f32 [Cout][Cin][3][3] (assigned), one launch. */
+typedef struct { float *dw[4]; } inv_policy_conv_grads;
+int  inv_policy_wgrad_to_module(const float *src, const inv_policy_conv_grads *out, void *stream);
+/* All four layers' LayerNorm weight / bias gradients in one launch, ADDED into the module's tensors gw[l], gb[l]: f32 [C_l][10][15]
+ * (zeroed by the caller); dy from inv_policy_grads, x^ from inv_policy_saved; `slices` sample slices (64 is a good value). */
+typedef struct { float *gw[4]; float *gb[4]; } inv_policy_ln_grads;
+int  inv_policy_param_grads_all(const inv_policy_grads *grads, const inv_policy_saved *saved, const inv_policy_ln_grads *out,
+                                int32_t slices, int32_t N, void *stream);
 /* Batch reductions for the LayerNorm gradients of one layer, one pass over dy and xhat (bf16 [N][E], E = 150 * C):
  * partial[s][0][e] = sum dy*xhat, partial[s][1][e] = sum dy over the samples n = s (mod slices); f32 [slices][2][E], every
  * entry written.  Adding the slices gives the LayerNorm weight / bias gradients in [pixel][channel] order. */

@@ -54,6 +54,14 @@ class InvPolicySaved(C.Structure):
     _fields_ = [("xhat", C.c_void_p * 4), ("act", C.c_void_p * 3), ("rstd", C.c_void_p)]
 
 
+class InvPolicyConvGrads(C.Structure):
+    _fields_ = [("dw", C.c_void_p * 4)]
+
+
+class InvPolicyLnGrads(C.Structure):
+    _fields_ = [("gw", C.c_void_p * 4), ("gb", C.c_void_p * 4)]
+
+
 class InvPolicyBandSaved(C.Structure):
     _fields_ = [("z", C.c_void_p * 4), ("stats", C.c_void_p)]
 
@@ -119,6 +127,8 @@ SIGNATURES = {
     "inv_policy_trunk_bwd": (C.c_int, [P(InvPolicyBwdParams), P(InvPolicySaved), _V, P(InvPolicyGrads), C.c_int32, _V]),
     "inv_policy_wgrad": (C.c_int, [C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_param_grads": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V]),
+    "inv_policy_param_grads_all": (C.c_int, [P(InvPolicyGrads), P(InvPolicySaved), P(InvPolicyLnGrads), C.c_int32, C.c_int32, _V]),
+    "inv_policy_wgrad_to_module": (C.c_int, [_V, P(InvPolicyConvGrads), _V]),
     "inv_policy_pack_conv": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V]),
     "inv_policy_pack_ln": (C.c_int, [_V, _V, C.c_int32, C.c_int32, _V, _V]),
     "inv_policy_trunk_banded_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int32]),

@@ -1351,6 +1351,9 @@ __global__ __launch_bounds__(WG_THREADS, PF ? 1 : 2) void k_policy_wgrad(const b
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int co = co_base + (mb0 + mi) * 16 + 4 * g + e;
+                    // [co][tap][ci]: a 16-lane group adds 64 consecutive bytes.  (Adding straight into the module's [co][ci][tap]
+                    // order -- lanes 36 B apart -- doubled the kernel's time: 0.60 -> 1.36 ms at 128 -> 128; the layout change is
+                    // k_wgrad_to_module's job, one launch for the four layers.)
                     atomicAdd(dw + ((size_t)co * 9 + t) * CINP + nb * 16 + r, acc[mi][t][e]);
                 }
     }
@@ -1388,6 +1391,93 @@ __global__ __launch_bounds__(256) void k_policy_param_grads(const bf16 *__restri
     *reinterpret_cast<float4 *>(o + 4) = make_float4(aw[4], aw[5], aw[6], aw[7]);
     *reinterpret_cast<float4 *>(o + stride) = make_float4(ab[0], ab[1], ab[2], ab[3]);
     *reinterpret_cast<float4 *>(o + stride + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
+}
+
+// [Cout][9][CinP] (k_policy_wgrad's order, the four layers back to back) -> the module's [Cout][Cin][3][3]
+struct WgUnpack {
+    const float *src;
+    float *dst[4];
+    __host__ __device__ static constexpr int cout(int l) { return l == 0 ? 32 : l == 1 ? 64 : 128; }
+    __host__ __device__ static constexpr int cin(int l) { return l == 0 ? 12 : l == 1 ? 32 : l == 2 ? 64 : 128; }
+    __host__ __device__ static constexpr int cinp(int l) { return l == 0 ? 16 : cin(l); }
+    __host__ __device__ static constexpr int size_mod(int l) { return cout(l) * cin(l) * 9; }
+    __host__ __device__ static constexpr int size_src(int l) { return cout(l) * cinp(l) * 9; }
+    __host__ __device__ static constexpr int total() { return size_mod(0) + size_mod(1) + size_mod(2) + size_mod(3); }
+};
+
+__global__ __launch_bounds__(256) void k_wgrad_to_module(WgUnpack u)
+{
+    int e = blockIdx.x * 256 + threadIdx.x;                              // one element of a module tensor
+    if (e >= WgUnpack::total()) return;
+    int l = 0, soff = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (e >= WgUnpack::size_mod(l)) { e -= WgUnpack::size_mod(l); soff += WgUnpack::size_src(l); ++l; }
+    const int cin = WgUnpack::cin(l), cinp = WgUnpack::cinp(l);
+    const int t = e % 9, ci = (e / 9) % cin, co = e / (9 * cin);
+    float *dst = l == 0 ? u.dst[0] : l == 1 ? u.dst[1] : l == 2 ? u.dst[2] : u.dst[3];
+    dst[e] = u.src[soff + ((size_t)co * 9 + t) * cinp + ci];
+}
+
+// All four layers' LayerNorm gradients in ONE launch, added straight into the module's tensors ([C][10][15] order: the parameters'
+// .grad): no per-slice partial buffers, no reduction / transposition launches afterwards (round 2: 4 launches + 4 torch reductions
+// + 8 layout copies per minibatch).  Item = (layer, pixel, 8 channels); blockIdx.y strides over the samples, four loads of each
+// tensor in flight per thread; 16 f32 atomics per thread at the end (destinations zeroed by the caller).
+struct PgAll { const bf16 *dy[4]; const bf16 *xh[4]; float *gw[4]; float *gb[4]; };
+
+__global__ __launch_bounds__(256) void k_policy_param_grads_all(PgAll a, int N)
+{
+    constexpr int I0 = P * 4, I1 = I0 + P * 8, I2 = I1 + P * 16, I3 = I2 + P * 16;     // item prefix sums: 32, 64, 128, 128 channels
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= I3) return;
+    const int layer = it < I0 ? 0 : it < I1 ? 1 : it < I2 ? 2 : 3;
+    const int base = layer == 0 ? 0 : layer == 1 ? I0 : layer == 2 ? I1 : I2;
+    const int c8 = layer == 0 ? 4 : layer == 1 ? 8 : 16;                                // 16-byte chunks per pixel
+    const int q = it - base, p = q / c8, part = q - p * c8;
+    const bf16 *dyl = layer == 0 ? a.dy[0] : layer == 1 ? a.dy[1] : layer == 2 ? a.dy[2] : a.dy[3];
+    const bf16 *xhl = layer == 0 ? a.xh[0] : layer == 1 ? a.xh[1] : layer == 2 ? a.xh[2] : a.xh[3];
+    const size_t stride = (size_t)P * c8 * 8;                                           // elements per sample
+    float aw[8], ab[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aw[j] = ab[j] = 0.0f;
+    constexpr int U = 4;
+    int n = blockIdx.y;
+    for (; n + (U - 1) * (int)gridDim.y < N; n += U * gridDim.y) {
+        bf16x8 d[U], x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t o = (size_t)(n + u * gridDim.y) * stride + (size_t)q * 8;
+            d[u] = *reinterpret_cast<const bf16x8 *>(dyl + o);
+            x[u] = *reinterpret_cast<const bf16x8 *>(xhl + o);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float df = (float)d[u][j];
+                aw[j] = fmaf(df, (float)x[u][j], aw[j]);
+                ab[j] += df;
+            }
+    }
+    for (; n < N; n += gridDim.y) {
+        const size_t o = (size_t)n * stride + (size_t)q * 8;
+        const bf16x8 d = *reinterpret_cast<const bf16x8 *>(dyl + o);
+        const bf16x8 x = *reinterpret_cast<const bf16x8 *>(xhl + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float df = (float)d[j];
+            aw[j] = fmaf(df, (float)x[j], aw[j]);
+            ab[j] += df;
+        }
+    }
+    float *gw = layer == 0 ? a.gw[0] : layer == 1 ? a.gw[1] : layer == 2 ? a.gw[2] : a.gw[3];
+    float *gb = layer == 0 ? a.gb[0] : layer == 1 ? a.gb[1] : layer == 2 ? a.gb[2] : a.gb[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = part * 8 + j;
+        atomicAdd(gw + (size_t)c * P + p, aw[j]);
+        atomicAdd(gb + (size_t)c * P + p, ab[j]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2023,6 +2113,21 @@ extern "C" int inv_policy_wgrad(int32_t layer, const void *x_bf16, const void *d
     }
 }
 
+// The four layers' weight gradients from the kernel's [Cout][9][CinP] order into the module's tensors [Cout][Cin][3][3] (assigned):
+// one launch instead of four slice / permute / copy chains.  src: the four [Cout][9][CinP] blocks back to back.
+extern "C" int inv_policy_wgrad_to_module(const float *src, const inv_policy_conv_grads *out, void *stream)
+{
+    if (!src || !out) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_wgrad_to_module: NULL argument");
+    pol::WgUnpack u;
+    for (int l = 0; l < 4; ++l) {
+        if (!out->dw[l]) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_wgrad_to_module: NULL tensor for layer %d", l);
+        u.dst[l] = out->dw[l];
+    }
+    u.src = src;
+    hipLaunchKernelGGL(pol::k_wgrad_to_module, dim3((pol::WgUnpack::total() + 255) / 256), dim3(256), 0, (hipStream_t)stream, u);
+    return launch_status("inv_policy_wgrad_to_module");
+}
+
 // weight / bias gradients of the banded trunk: N samples of the 32 x 32 board = 8 N band units of 128 dz pixels (WgGeoBand)
 extern "C" int inv_policy_band_wgrad(int32_t layer, int32_t height, int32_t width, const void *x_bf16, const void *dz_bf16, float *dw, float *dbias,
                                      int32_t N, void *stream)
@@ -2040,6 +2145,22 @@ extern "C" int inv_policy_band_wgrad(int32_t layer, int32_t height, int32_t widt
     case 2: return launch_wgrad<64, 128, 4, 4, true, pol::WgGeoBand>(x_bf16, dz_bf16, dw, dbias, units, st);
     default: return launch_wgrad<128, 128, 4, 8, true, pol::WgGeoBand>(x_bf16, dz_bf16, dw, dbias, units, st);
     }
+}
+
+extern "C" int inv_policy_param_grads_all(const inv_policy_grads *grads, const inv_policy_saved *saved, const inv_policy_ln_grads *out,
+                                          int32_t slices, int32_t N, void *stream)
+{
+    if (!grads || !saved || !out || N < 0 || slices < 1) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_param_grads_all: NULL argument, N < 0 or slices < 1");
+    pol::PgAll a;
+    for (int l = 0; l < 4; ++l) {
+        if (!grads->dy[l] || !saved->xhat[l] || !out->gw[l] || !out->gb[l]) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_param_grads_all: NULL tensor for layer %d", l);
+        a.dy[l] = reinterpret_cast<const pol::bf16 *>(grads->dy[l]); a.xh[l] = reinterpret_cast<const pol::bf16 *>(saved->xhat[l]);
+        a.gw[l] = out->gw[l]; a.gb[l] = out->gb[l];
+    }
+    if (N == 0) return INV_OK;
+    const int items = pol::P * (4 + 8 + 16 + 16), sl = slices < N ? slices : N;
+    hipLaunchKernelGGL(pol::k_policy_param_grads_all, dim3((items + 255) / 256, sl), dim3(256), 0, (hipStream_t)stream, a, (int)N);
+    return launch_status("inv_policy_param_grads_all");
 }
 
 extern "C" int inv_policy_param_grads(const void *dy_bf16, const void *xhat_bf16, float *partial, int32_t slices,

@@ -29,7 +29,8 @@ from .fused_policy import _CIN_PAD, _pack_conv, pack_conv, pack_ln
 _COUT = (32, 64, 128, 128)
 _CIN = (12, 32, 64, 128)
 _CINP = (16, 32, 64, 128)          # channels of the wgrad kernel's x operand (layer 1: 12 planes + 4 zero channels)
-_RED_SLICES = 128               # sample slices of the LayerNorm / bias gradient reduction (partials summed by torch)
+_RED_SLICES = 128               # sample slices of the banded path's LayerNorm gradient reduction (partials summed by torch)
+_PG_SLICES = 64                 # sample slices of inv_policy_param_grads_all (each adds its sums with f32 atomics)
 _WGRAD_CHUNK = 2048            # samples per im2col GEMM (bounds the 9x-expanded operand to ~0.7 GB)
 
 
@@ -126,7 +127,12 @@ class _TrunkTrainFn(torch.autograd.Function):
         return feat
 
     @staticmethod
-    def backward(ctx, dfeat):
+    def backward(ctx, dfeat, out=None, mid=None):
+        """out: the 16 gradient tensors in parameter order (conv weight [Cout,Cin,3,3], conv bias, LayerNorm weight / bias [C,10,15]),
+        ZEROED: the kernels add into them in the module's own layouts -- the direct path (loss_and_grads) passes the parameters'
+        .grad slices of the flat bucket, autograd gets fresh tensors.  mid(): called on the main stream after the backward kernel is
+        queued and the LayerNorm reduction has been put on the side stream -- the direct path runs the heads' first-Linear
+        weight-gradient GEMM there (MFMA-bound, beside the HBM-bound reduction)."""
         lib = L.load()
         sv = ctx.saved_tensors
         obs, rstd = sv[0], sv[1]
@@ -150,6 +156,16 @@ class _TrunkTrainFn(torch.autograd.Function):
         for i in range(3):
             saved.act[i] = act[i].data_ptr()
         saved.rstd = rstd.data_ptr()
+        if out is None:
+            out = []
+            for i in range(4):
+                c = _COUT[i]
+                out += [torch.zeros((c, _CIN[i], 3, 3), dtype=torch.float32, device=dev), torch.zeros((c,), dtype=torch.float32, device=dev),
+                        torch.zeros((c, 10, 15), dtype=torch.float32, device=dev), torch.zeros((c, 10, 15), dtype=torch.float32, device=dev)]
+        else:
+            out = list(out)
+            if len(out) != 16 or any(t.dtype != torch.float32 or not t.is_contiguous() for t in out):
+                raise ValueError("backward(out=...): 16 contiguous f32 tensors in parameter order")
         with torch.cuda.device(dev):
             rc = lib.inv_policy_trunk_bwd(C.byref(bp), C.byref(saved), _ptr(dfeat), C.byref(grads), n,
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -158,35 +174,42 @@ class _TrunkTrainFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = lib.inv_policy_obs_to_x0(_ptr(obs), 1 if ctx.bits else 0, _ptr(x0), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.raise_for(rc, lib)
-        # The LayerNorm reductions (HBM-bound: dy and x^ once, 3.4 GB) run on a side stream beside the weight-gradient kernels
-        # (MFMA-bound, 3 GB of x / dz): both only read what the backward kernel wrote.  The main stream waits for the side
-        # stream before returning, so every tensor used there outlives its use.  INVERSUS_PG_STREAM=0: one stream.
+        # The LayerNorm reductions (HBM-bound: dy and x^ once, 3.4 GB; ONE launch for the four layers, added straight into the
+        # module-layout gradients) run on a side stream beside MFMA-bound work of the main stream that only reads what the
+        # backward kernel wrote: `mid` (the first Linear's weight-gradient GEMM) and the convolutions' weight gradients.  The main
+        # stream waits for the side stream before returning, so every tensor used there outlives its use.  INVERSUS_PG_STREAM=0:
+        # one stream.
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if os.environ.get("INVERSUS_PG_STREAM", "1") != "0" else main
         if side is not main:
             side.wait_stream(main)
-        ln_grads = []
-        with torch.cuda.stream(side):
-            for i in range(4):
-                c = _COUT[i]
-                slices = max(1, min(n, _RED_SLICES))
-                part = torch.empty((slices, 2, 150, c), dtype=torch.float32, device=dev)   # per-slice sums of dy*x^, dy
-                with torch.cuda.device(dev):
-                    rc = lib.inv_policy_param_grads(_ptr(dy[i]), _ptr(xhat[i]), _ptr(part), slices, 150 * c, n,
-                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
-                L.raise_for(rc, lib)
-                red = part.sum(dim=0)
-                if side is not main:
-                    red.record_stream(main)                                              # consumed on the main stream after the join
-                ln_grads.append((red[0].t().reshape(c, 10, 15), red[1].t().reshape(c, 10, 15)))
-        out = [None]
+        lng = L.InvPolicyLnGrads()
         for i in range(4):
-            x_in = x0 if i == 0 else act[i - 1]
-            dw, db = _wgrad(i, x_in, dz[i])
-            out += [dw, db, ln_grads[i][0], ln_grads[i][1]]
+            lng.gw[i], lng.gb[i] = out[4 * i + 2].data_ptr(), out[4 * i + 3].data_ptr()
+        with torch.cuda.stream(side):
+            with torch.cuda.device(dev):
+                rc = lib.inv_policy_param_grads_all(C.byref(grads), C.byref(saved), C.byref(lng), _PG_SLICES, n,
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            L.raise_for(rc, lib)
+        if mid is not None:
+            mid()
+        # weight gradients: the kernel's [Cout][9][CinP] blocks of the four layers in one zeroed scratch, converted to the module's
+        # [Cout][Cin][3][3] by one launch; the conv bias gradients are added straight into their tensors
+        sizes = [_COUT[i] * 9 * _CINP[i] for i in range(4)]
+        scratch = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        cg, off = L.InvPolicyConvGrads(), 0
+        with torch.cuda.device(dev):
+            for i in range(4):
+                x_in = x0 if i == 0 else act[i - 1]
+                rc = lib.inv_policy_wgrad(i, _ptr(x_in), _ptr(dz[i]), C.c_void_p(scratch.data_ptr() + 4 * off), _ptr(out[4 * i + 1]), n,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                L.raise_for(rc, lib)
+                cg.dw[i] = out[4 * i].data_ptr()
+                off += sizes[i]
+            L.raise_for(lib.inv_policy_wgrad_to_module(_ptr(scratch), C.byref(cg), C.c_void_p(torch.cuda.current_stream().cuda_stream)), lib)
         if side is not main:
             main.wait_stream(side)
-        return tuple(out)
+        return (None, *out)
 
 
 class _TrunkTrainBandedFn(torch.autograd.Function):
@@ -339,6 +362,25 @@ class FusedTrainPolicy:
         w1 = (hparams[0], hparams[6])                                     # 39.3 of the 41 MB: written in place by the unpack kernel
         if all(q.grad.is_contiguous() for q in w1):
             hctx.fc1_grad_out = [q.grad for q in w1]
+        if self.trunk_fn is _TrunkTrainFn:
+            # 15 x 10: the heads' backward in two halves around the trunk's backward kernel -- d features first (the trunk needs it),
+            # then, once that kernel and the LayerNorm reduction (side stream, HBM-bound) are queued, the first Linear's weight-
+            # gradient GEMM (MFMA-bound) and the small head gradients; the trunk's gradients are ADDED into the (zeroed) .grad slices
+            dfeat = HD._HeadsTrainFn.backward_features(hctx, dlogits, dvalues.reshape(-1, 1))
+            tgrads = [q.grad for q in tparams]
+            torch._foreach_zero_(tgrads)
+
+            def mid():
+                hg = HD._HeadsTrainFn.backward_params(hctx)
+                pairs = [(q.grad, g) for q, g in zip(hparams, hg) if g is not q.grad]
+                torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
+                if after_heads is not None:
+                    after_heads()
+            if os.environ.get("INVERSUS_FC1_MID", "1") == "0":             # A/B: the round-2 order (all of the heads' backward first)
+                mid()
+                mid = None
+            self.trunk_fn.backward(tctx, dfeat, out=tgrads, mid=mid)
+            return means
         hg = HD._HeadsTrainFn.backward(hctx, dlogits, dvalues.reshape(-1, 1))
         pairs = [(q.grad, g) for q, g in zip(hparams, hg[2:]) if g is not q.grad]
         torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])

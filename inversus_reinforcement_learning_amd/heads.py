@@ -162,6 +162,13 @@ class _HeadsTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits, dvalue):
+        dfeat = _HeadsTrainFn.backward_features(ctx, dlogits, dvalue)
+        return (dfeat, None, *_HeadsTrainFn.backward_params(ctx))
+
+    @staticmethod
+    def backward_features(ctx, dlogits, dvalue):
+        """First half: inv_heads_bwd (everything behind the first Linear, the small gradients added per block) and
+        d features = d pre @ W1 -- what the trunk's backward waits for.  Leaves what the second half needs on ctx."""
         lib = L.load()
         feat, extra, h, a2 = ctx.saved_tensors
         ops, P, B, dev = ctx.ops, ctx.pixels, feat.shape[0], feat.device
@@ -176,13 +183,25 @@ class _HeadsTrainFn(torch.autograd.Function):
             rc = lib.inv_heads_bwd(C.byref(ops.params), _ptr(dlogits), _ptr(dvalue), _ptr(h), _ptr(a2), _ptr(extra), _ptr(dpre),
                                    _ptr(dpre_t) if dpre_t is not None else None, _ptr(da2), C.byref(gr), B, _stream())
         L.raise_for(rc, lib)
+        ctx.mid_state = (small, dpre, dpre_t, da2)
         # the library's kernels for K-contiguous operands are the fast ones (tools/fc1_gemm_ab.py): both products get a transposed copy
-        dfeat = None
-        if ctx.needs_input_grad[0]:
-            wft = torch.empty((128 * P, 2 * HID), dtype=torch.bfloat16, device=dev)
-            with torch.cuda.device(dev):
-                L.raise_for(lib.inv_transpose_bf16(_ptr(ops.wf), 2 * HID, 128 * P, _ptr(wft), _stream()), lib)
-            dfeat = dpre @ wft.t()                                                     # bf16 [B, 128 P]
+        needs = getattr(ctx, "needs_input_grad", (True,))
+        if not needs[0]:
+            return None
+        wft = torch.empty((128 * P, 2 * HID), dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            L.raise_for(lib.inv_transpose_bf16(_ptr(ops.wf), 2 * HID, 128 * P, _ptr(wft), _stream()), lib)
+        return dpre @ wft.t()                                                          # bf16 [B, 128 P]
+
+    @staticmethod
+    def backward_params(ctx):
+        """Second half: the first Linear's weight gradient d pre^T @ features (the big GEMM), its unpacking into the module's
+        column order, dW2 and the small gradients -> the 12 head tensors' gradients in head_tensors() order."""
+        lib = L.load()
+        feat, extra, h, a2 = ctx.saved_tensors
+        P, B, dev = ctx.pixels, feat.shape[0], feat.device
+        small, dpre, dpre_t, da2 = ctx.mid_state
+        ctx.mid_state = None
         dwf = (dpre_t if dpre_t is not None else dpre.t()) @ feat                      # bf16 [512, 128 P], f32 accumulation over B
         gw1 = []
         with torch.cuda.device(dev):
@@ -196,11 +215,11 @@ class _HeadsTrainFn(torch.autograd.Function):
         part = torch.bmm(da2.view(G, B // G, 2 * MID).transpose(1, 2), h.view(G, B // G, 2 * HID))       # bf16 [G, 256, 512]
         dw2 = part.float().sum(0)
         gw2 = [dw2[:MID, :HID].contiguous(), dw2[MID:, HID:].contiguous()]
-        out = [dfeat, None]
+        out = []
         for i in range(2):                                                             # order of head_tensors(): W1, b1, W2, b2, W3, b3
             out += [gw1[i], small.view("db1")[HID * i:HID * (i + 1)], gw2[i], small.view(f"db2_{i}"),
                     small.view(f"dw3_{i}").view(-1, MID), small.view(f"db3_{i}")]
-        return tuple(out)
+        return out
 
 
 def heads_train(policy, feat, extra):

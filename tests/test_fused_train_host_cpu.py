@@ -75,5 +75,7 @@ def test_fused_train_policy_needs_a_gpu_policy():
     from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
     with pytest.raises(RuntimeError):
         FT.FusedTrainPolicy(InversusCNNPolicy(12, 10, 15, 4))
+    with pytest.raises(RuntimeError):
+        FT.FusedTrainPolicy(InversusCNNPolicy(12, 32, 32, 4))             # round 3: the 32 x 32 board trains through the banded kernels
     with pytest.raises(ValueError):
-        FT.FusedTrainPolicy(InversusCNNPolicy(12, 32, 32, 4))
+        FT.FusedTrainPolicy(InversusCNNPolicy(12, 16, 16, 4))             # no fused trunk for other boards

@@ -169,10 +169,11 @@ def test_training_loop_on_the_32x32_board():
     res = training.train_vs_dummy(num_envs=32, total_steps=32 * 128, width=32, height=32, log_dir=None, opponent_difficulty="hard",
                                   seed=1, verbose=False, agent_kwargs=dict(batch_size=1024, epochs=1))
     assert res["steps"] == 32 * 128 and all(np.isfinite(res[k]) for k in ("policy_loss", "value_loss", "entropy"))
-    # round 2: the fused ACTOR exists for 32 x 32 (banded trunk kernel); the fused UPDATE is 15 x 10 only and says so
+    # round 2: the fused ACTOR exists for 32 x 32 (banded trunk kernel) ...
     res = training.train_vs_dummy(num_envs=32, total_steps=32 * 128, width=32, height=32, log_dir=None, opponent_difficulty="hard", seed=1,
                                   verbose=False, agent_kwargs=dict(batch_size=1024, epochs=1, fused_act=True))
     assert res["steps"] == 32 * 128 and all(np.isfinite(res[k]) for k in ("policy_loss", "value_loss", "entropy"))
-    with pytest.raises(ValueError):
-        training.train_vs_dummy(num_envs=8, total_steps=8 * 128, width=32, height=32, log_dir=None, seed=1, verbose=False,
-                                agent_kwargs=dict(fused_act=True, fused_update=True))
+    # ... round 3: and so does the fused UPDATE (banded training kernels, tests/test_gpu_fused_train_32x32.py)
+    res = training.train_vs_dummy(num_envs=8, total_steps=8 * 128, width=32, height=32, log_dir=None, seed=1, verbose=False,
+                                  agent_kwargs=dict(fused_act=True, fused_update=True, batch_size=512, epochs=1))
+    assert res["steps"] == 8 * 128 and all(np.isfinite(res[k]) for k in ("policy_loss", "value_loss", "entropy"))
