@@ -215,8 +215,14 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
 
 
 // The same step with FOUR envs per wave (inv_step4.h): full steps only (all four phases), no mask.  WPB waves per block.
+// The multi-step (inv_rollout) instantiations are asked for 4 waves per SIMD (<= 128 VGPRs; 15x10: 158 -> 128, no scratch): the
+// launch's 4 096 waves are then all resident (16 per CU) instead of 3 072 + a second round of 1 024 -- the packed-observation
+// rollout (compute-bound) 8.56 -> 7.07 us per step, the f32 rollouts (store-bound) unchanged (same-box A/B, round 3).
+#ifndef INV_ROLLOUT_MIN_WAVES
+#define INV_ROLLOUT_MIN_WAVES 4
+#endif
 template <class D, bool SINGLE, int WPB>
-__global__ __launch_bounds__(kWave * WPB) void k_step4(StepArgs a)
+__global__ __launch_bounds__(kWave * WPB, SINGLE ? 1 : INV_ROLLOUT_MIN_WAVES) void k_step4(StepArgs a)
 {
     using namespace inv4;
     using LL = Lds4<D>;
