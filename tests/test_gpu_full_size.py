@@ -94,6 +94,49 @@ def test_c3_selfplay_collector_and_fused_update_at_size():
     b.check()
 
 
+def test_c5_selfplay_collector_and_fused_update_at_size():
+    """BASELINE config C5 with the policy in the loop AND the fused update (round 3) at 16 384 envs: 4 self-play vector steps on the
+    32 x 32 board with packed observations (384 words per env-step), two env columns blocks replayed by the oracle from the
+    recorded actions, then one PPO epoch through the banded training kernels (4 minibatches of 16 384 samples)."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    from oracle import oracle as orc
+    n, T, W, H = 16384, 4, 32, 32
+    seeds = 90000 + np.arange(n, dtype=np.int64)
+    b = DeviceEnvBatch(n, W, H, opponent="selfplay")
+    b.seed(seeds); b.reset()
+    torch.manual_seed(0)
+    agent = PPOAgent(InversusCNNPolicy(12, H, W, 4), fused_act=True, fused_update=True, batch_size=n, epochs=1)
+    assert agent.direct_grads and agent.fused.banded
+    opp = FusedPolicy(InversusCNNPolicy(12, H, W, 4).cuda().eval(), actor_only=True)
+    col = RolloutCollector(b, agent, opp, record_opponent_actions=True)
+    assert col.packed and col.collect(T) == T * n
+    assert all(g.dtype == torch.int32 and tuple(g.shape) == (n, 384) for g in agent.obs_grid_buffer)
+    for off in (0, n - 64):
+        cols = slice(off, off + 64)
+        ob = orc.OracleBatch(64, W, H)
+        ob.seed_reset(seeds[cols])
+        for t in range(T):
+            a1 = agent.action_buffer[t][cols].cpu().numpy().astype(np.uint8)
+            a2 = col.opponent_actions[t][cols].cpu().numpy().astype(np.uint8)
+            o_obs, _, o_r32, _, o_done, _ = ob.step(a1, a2)
+            assert bits_eq(agent.reward_buffer[t][cols].cpu().numpy(), o_r32), (off, t)
+            assert np.array_equal(agent.done_buffer[t][cols].cpu().numpy(), o_done.astype(bool)), (off, t)
+            nxt = (agent.obs_grid_buffer[t + 1] if t + 1 < T else col.obs[0])[cols].cpu().numpy().view(np.uint32)
+            want = np.packbits(o_obs.reshape(64, -1) != 0, axis=1, bitorder="little").view(np.uint32)
+            assert np.array_equal(nxt, want), (off, t)
+    before = agent.flat_adam.flat.clone()
+    stats = agent.update()
+    # (a random-init 32 x 32 policy is less uniform than the 15 x 10 one: its logits sum over 131 072 features)
+    assert all(np.isfinite(stats[k]) for k in ("policy_loss", "value_loss", "entropy")) and 0.5 < stats["entropy"] <= np.log(13) + 1e-3
+    assert bool(torch.isfinite(agent.flat_adam.flat).all()) and float((agent.flat_adam.flat - before).abs().max()) > 0
+    b.check()
+
+
 def test_c5_32x32_hard_16384_blocks_vs_oracle():
     import torch
     from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
