@@ -265,6 +265,60 @@ def side_measurements(torch, np, n):
         return {"T": T, "us_per_vector_step": round(us, 2), "GBps": round(by / us / 1e3, 1), "env_steps_per_s": round(n / us * 1e6)}
     guard("step vs_dummy_easy 15x10 into 32 DISTINCT output buffers (3.8 GB footprint: streams to HBM)", streaming_cfg)
 
+    def two_shards_cfg():
+        """The GPU's 16 384 envs as TWO independent shards of 8 192 (global env indices [0, 8192) and [8192, 16384): the same envs,
+        the same results) stepped on two HIP streams -- the way the shards of different GPUs are independent.  One shard's launch
+        boundary and the ~2 us in front of its first store then run under the other shard's observation stream.  us per FULL vector
+        step (both shards) from the wall clock over 512 steps, median of 5; cache-resident (one output buffer per shard) and
+        streaming (32 distinct buffers per shard); the one-batch figures of the same process beside them."""
+        from inversus_reinforcement_learning_amd.device_env import StepResult
+
+        def make(m, off, T, stream):
+            with torch.cuda.stream(stream):
+                b = DeviceEnvBatch(m, 15, 10, K, opponent="dummy", difficulty="easy", opp_seed=1, env_offset=off)
+                b.seed(off + np.arange(m, dtype=np.int64)); b.reset()
+                acts = torch.stack([b.uniform_actions(5, t) for t in range(64)])
+                o = b._alloc_out((T,), True, False, False, None)
+                outs = [StepResult(**{k2: (getattr(o, k2)[j] if getattr(o, k2) is not None else None) for k2 in StepResult.__slots__}) for j in range(T)]
+                st = [b.make_stepper(outs[j % T], None, auto_reset=True) for j in range(64)]          # bound to `stream`
+            stream.synchronize()
+            return b, acts, o, st
+
+        def run(parts, reps=512):
+            for t in range(64):
+                for _, acts, _, st in parts:
+                    st[t % 64](acts[t % 64].data_ptr())
+            torch.cuda.synchronize()
+            out_ = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for t in range(reps):
+                    for _, acts, _, st in parts:
+                        st[t % 64](acts[t % 64].data_ptr())
+                torch.cuda.synchronize()
+                out_.append((time.perf_counter() - t0) / reps * 1e6)
+            for b_, *_ in parts:
+                b_.check()
+            return sorted(out_)[2]
+
+        by = algorithmic_bytes_per_env_step() * n
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        res = {}
+        for T, tag in ((1, "cache_resident"), (32, "streaming")):
+            one = [make(n, 0, T, s1)]
+            us1 = run(one)
+            del one
+            torch.cuda.empty_cache()
+            two = [make(n // 2, 0, T, s1), make(n // 2, n // 2, T, s2)]
+            us2 = run(two)
+            del two
+            torch.cuda.empty_cache()
+            res[tag] = {"us_per_full_vector_step_one_batch_one_stream": round(us1, 2), "us_per_full_vector_step_two_shards_two_streams": round(us2, 2),
+                        "env_steps_per_s_two_shards": round(n / us2 * 1e6), "GBps_two_shards": round(by / us2 / 1e3, 1),
+                        "frac_of_8000_GBps_two_shards": round(by / us2 / 1e3 / HBM_PEAK_GBS, 3)}
+        return res
+    guard("two independent env shards of 8192 on two HIP streams (vs_dummy_easy 15x10 f32, wall clock per full 16384-env step)", two_shards_cfg)
+
     def gae_cfg():
         T = 128
         r = torch.randn(T, n, device="cuda"); v = torch.randn(T, n, device="cuda")
@@ -717,6 +771,9 @@ def main():
             del b, out, a1_all, step
             torch.cuda.empty_cache()
             res["extras"] = side_measurements(torch, np, n)
+            two = res["extras"].get("two independent env shards of 8192 on two HIP streams (vs_dummy_easy 15x10 f32, wall clock per full 16384-env step)")
+            if isinstance(two, dict):                                     # also inside `roofline`, so that it survives a parser that keeps the contract's keys
+                res["roofline"]["two_shards_on_two_streams"] = two
         if c4 is not None:
             res.setdefault("extras", {})["C4 selfplay PPO iteration"] = c4
         print(json.dumps(res), flush=True)

@@ -24,3 +24,10 @@ if [ -z "$NO_BENCH" ]; then
   find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv; rm -rf $O/kt
   head -5 $O/bench_kernel_stats.csv | cut -c1-220; python3 -c "import json;d=json.load(open('$O/bench.json'));print(json.dumps({k:d[k] for k in ('value','ms_per_step','roofline')}, indent=1))"
 fi
+if [ -z "$NO_UPDATE" ]; then
+  python3 tools/agent_update_profile.py > $O/update_torch_profile.txt 2>&1; grep "update ms" $O/update_torch_profile.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_upd -- python3 tools/agent_update_profile.py --no-prof > $O/update_under_rocprof.json 2> $O/kt_upd.err; echo "kt update rc=$?"
+  find $O/kt_upd -name "*kernel_stats.csv" | head -1 | xargs -I{} head -40 {} > $O/update_kernel_stats_top40.csv; rm -rf $O/kt_upd
+  python3 tools/gae_kernel_time.py > $O/gae_kernel_time.json 2>/dev/null; cat $O/gae_kernel_time.json | tr -d '\n'; echo
+  python3 tools/two_stream_steps.py > $O/two_stream_steps.json 2>/dev/null; cat $O/two_stream_steps.json | tr -d '\n'; echo
+fi
