@@ -273,10 +273,13 @@ def side_measurements(torch, np, n):
         streaming (32 distinct buffers per shard); the one-batch figures of the same process beside them."""
         from inversus_reinforcement_learning_amd.device_env import StepResult
 
+        from inversus_reinforcement_learning_amd.device_env import EnvShards
+
         def make(m, off, T, stream):
+            sh = EnvShards(m, 1, seed=0, env_offset=off, streams=[stream], width=15, height=10, max_bullets=K, opponent="dummy",
+                           difficulty="easy", opp_seed=1).shards[0]
             with torch.cuda.stream(stream):
-                b = DeviceEnvBatch(m, 15, 10, K, opponent="dummy", difficulty="easy", opp_seed=1, env_offset=off)
-                b.seed(off + np.arange(m, dtype=np.int64)); b.reset()
+                b = sh.batch
                 acts = torch.stack([b.uniform_actions(5, t) for t in range(64)])
                 o = b._alloc_out((T,), True, False, False, None)
                 outs = [StepResult(**{k2: (getattr(o, k2)[j] if getattr(o, k2) is not None else None) for k2 in StepResult.__slots__}) for j in range(T)]

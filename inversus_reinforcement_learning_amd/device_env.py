@@ -268,6 +268,59 @@ class DeviceEnvBatch:
             torch.cuda.current_stream().synchronize()      # keep the staging tensors alive until consumed
 
 
+class EnvShards:
+    """The envs of ONE GPU as `shards` independent DeviceEnvBatch shards (contiguous global index ranges, so results do not depend on
+    the cut), each bound to a HIP stream of its own.  Shards never exchange data -- the way the shards of different GPUs do not -- so
+    their launch chains may run free: one shard's launch boundary and the ~2 us before its first observation store then hide under
+    another shard's store stream (two shards of 8 192 envs: 18.6 -> 15.4 us per full 16 384-env step on a cache-resident buffer,
+    25.3 -> 20.6 us streaming).  It is for callers that can consume shards independently (a double-buffered
+    collector: step shard A while the policy evaluates shard B); behind a synchronous `step()` that returns every env's observation
+    the chains would run in lockstep and nothing is gained.
+
+        shards = EnvShards(16384, 2, opponent="dummy")            # seeds: base + global index, like MultiEnvRunner
+        for sh in shards:                                          # sh.batch, sh.stream, sh.offset, sh.count
+            with torch.cuda.stream(sh.stream): ...                 # every call on a shard goes to its stream
+    """
+
+    class Shard:
+        __slots__ = ("batch", "stream", "offset", "count")
+
+        def __init__(self, batch, stream, offset, count):
+            self.batch, self.stream, self.offset, self.count = batch, stream, offset, count
+
+    def __init__(self, num_envs, shards=2, *, seed=0, env_offset=0, streams=None, **batch_kwargs):
+        if shards < 1 or num_envs < shards:
+            raise ValueError("EnvShards: need 1 <= shards <= num_envs")
+        self.num_envs = int(num_envs)
+        base, rem = divmod(self.num_envs, int(shards))
+        self.shards, off = [], int(env_offset)
+        for k in range(int(shards)):
+            cnt = base + (1 if k < rem else 0)
+            st = streams[k] if streams is not None else torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                b = DeviceEnvBatch(cnt, env_offset=off, **batch_kwargs)
+                b.seed(int(seed) + off + np.arange(cnt, dtype=np.int64))
+                b.reset()
+            st.synchronize()
+            self.shards.append(EnvShards.Shard(b, st, off, cnt))
+            off += cnt
+
+    def __iter__(self):
+        return iter(self.shards)
+
+    def __len__(self):
+        return len(self.shards)
+
+    def synchronize(self):
+        for sh in self.shards:
+            sh.stream.synchronize()
+
+    def check(self):
+        for sh in self.shards:
+            with torch.cuda.stream(sh.stream):
+                sh.batch.check()
+
+
 def unpack_obs(bits, height=10, width=15, out=None):
     """Packed observations [..., OW] int32 (INV_STEP_OBS_BITS) -> f32 planes [..., 12, H, W]; exact."""
     lib = L.load()
