@@ -376,7 +376,12 @@ class FusedTrainPolicy:
                 torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
                 if after_heads is not None:
                     after_heads()
-            if os.environ.get("INVERSUS_FC1_MID", "1") == "0":             # A/B: the round-2 order (all of the heads' backward first)
+            # Default: all of the heads' backward first (the round-2 order: their gradients -- 39 of the 41 MB -- are complete before
+            # the trunk's backward starts, so a multi-GPU run's early all-reduce travels under it).  INVERSUS_FC1_MID=1 moves the
+            # first Linear's weight-gradient GEMM behind the trunk's backward kernel, beside the LayerNorm reduction: measured equal
+            # (6.59 vs 6.57-6.61 ms, tools/update_ab.py), and a library stream-K GEMM next to another stream's kernels is one
+            # concurrency pattern less to depend on.
+            if os.environ.get("INVERSUS_FC1_MID", "0") != "1":
                 mid()
                 mid = None
             self.trunk_fn.backward(tctx, dfeat, out=tgrads, mid=mid)
