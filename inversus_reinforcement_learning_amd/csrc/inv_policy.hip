@@ -649,7 +649,8 @@ __device__ __forceinline__ void band_load_obs(bf16 *tile, const uint32_t *obw, c
 
 // conv3x3 on the band + bias (+ residual), statistics, z (bf16) back to the scratch through the tile
 template <class G, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL>
-__device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile, bf16 *__restrict__ zout, int band, int lane, int m0, int n0, float &s, float &ss)
+__device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile, bf16 *__restrict__ zout, int band, int lane, int m0, int n0, float &s, float &ss,
+                                          unsigned long long &stamp_prev, int slot0 = 0)
 {
     constexpr int KPT = CIN / 32, KS = 9 * KPT;
     asm volatile("" : "+v"(lane));
@@ -710,7 +711,9 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
             ss += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
         }
     }
+    STAMP(slot0 + 1);                                                // band GEMM + statistics
     __syncthreads();                                                 // every wave's GEMM reads of the band are done
+    STAMP(slot0 + 2);                                                // wait for the other waves' GEMMs
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         const int ch0 = (m0 + mi) * 16 + 4 * kg;
@@ -732,6 +735,7 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
         dst[q] = *reinterpret_cast<const bf16x8 *>(tile + ((rr + 1) * G::PWB + x + 1) * CSF + part * 8);
     }
     __syncthreads();                                                 // the tile is rebuilt by the next band
+    STAMP(slot0 + 3);                                                // z through the tile to global memory
 }
 
 __device__ __forceinline__ void band_stats(float s, float ss, float cnt, float *red, float &rstd, float &shift)
@@ -786,13 +790,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         bf16 *const z3 = SAVE ? reinterpret_cast<bf16 *>(sv.z[2]) + (size_t)n * G::P * 128 : zA0;
         bf16 *const z4 = SAVE ? reinterpret_cast<bf16 *>(sv.z[3]) + (size_t)n * G::P * 128 : zB0;
         float s, ss, rstd, shift;
+#ifdef INV_POLICY_STAMPS
+        unsigned long long stamp_prev = stamp_now();                  // phase shares: tools/banded_stamps.py
+#else
+        unsigned long long stamp_prev = 0;
+#endif
         // layer 1: 12 (-> 32) -> 32 channels
         s = ss = 0.0f;
 #pragma unroll 1
         for (int band = 0; band < G::NB; ++band) {
             band_load_obs<G, R, BITS>(tile, obw, planes, band);
             __syncthreads();
-            band_conv<G, R, 32, 32, 1, G::NT / 2, false>(prm.layer[0], tile, z1, band, lane_i, wave & 1, (wave >> 1) * (G::NT / 2), s, ss);
+            STAMP(0);
+            band_conv<G, R, 32, 32, 1, G::NT / 2, false>(prm.layer[0], tile, z1, band, lane_i, wave & 1, (wave >> 1) * (G::NT / 2), s, ss, stamp_prev, 0);
         }
         band_stats(s, ss, (float)(32 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 0] = rstd; sv.stats[(size_t)n * 8 + 1] = shift; }
@@ -802,7 +812,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         for (int band = 0; band < G::NB; ++band) {
             band_load_norm<G, R, 32>(tile, z1, prm.layer[0].ln, rstd, shift, band);
             __syncthreads();
-            band_conv<G, R, 32, 64, 1, G::NT, false>(prm.layer[1], tile, z2, band, lane_i, wave, 0, s, ss);
+            STAMP(4);
+            band_conv<G, R, 32, 64, 1, G::NT, false>(prm.layer[1], tile, z2, band, lane_i, wave, 0, s, ss, stamp_prev, 4);
         }
         band_stats(s, ss, (float)(64 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 2] = rstd; sv.stats[(size_t)n * 8 + 3] = shift; }
@@ -812,7 +823,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         for (int band = 0; band < G::NB; ++band) {
             band_load_norm<G, R, 64>(tile, z2, prm.layer[1].ln, rstd, shift, band);
             __syncthreads();
-            band_conv<G, R, 64, 128, 2, G::NT, false>(prm.layer[2], tile, z3, band, lane_i, wave * 2, 0, s, ss);
+            STAMP(8);
+            band_conv<G, R, 64, 128, 2, G::NT, false>(prm.layer[2], tile, z3, band, lane_i, wave * 2, 0, s, ss, stamp_prev, 8);
         }
         band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 4] = rstd; sv.stats[(size_t)n * 8 + 5] = shift; }
@@ -822,7 +834,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         for (int band = 0; band < G::NB; ++band) {
             band_load_norm<G, R, 128>(tile, z3, prm.layer[2].ln, rstd, shift, band);
             __syncthreads();
-            band_conv<G, R, 128, 128, 2, G::NT, true>(prm.layer[3], tile, z4, band, lane_i, wave * 2, 0, s, ss);
+            STAMP(12);
+            band_conv<G, R, 128, 128, 2, G::NT, true>(prm.layer[3], tile, z4, band, lane_i, wave * 2, 0, s, ss, stamp_prev, 12);
         }
         band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 6] = rstd; sv.stats[(size_t)n * 8 + 7] = shift; }
@@ -851,6 +864,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
             }
         }
         __syncthreads();                                             // zB / obw are rewritten by the next sample
+        STAMP(16);                                                   // statistics + feature pass
     }
 }
 
@@ -1704,7 +1718,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_band_conv_t(inv_policy_layer lp,
         for (int band = 0; band < G::NB; ++band) {
             band_load_raw<G, R, CIN>(tile, src, band);
             __syncthreads();
-            band_conv<G, R, CIN, COUT, MW, NW, RESIDUAL>(lp, tile, dst, band, lane_i, m0, n0, s, ss);
+            unsigned long long stamp_prev = 0;
+            band_conv<G, R, CIN, COUT, MW, NW, RESIDUAL>(lp, tile, dst, band, lane_i, m0, n0, s, ss, stamp_prev, 24);
         }
     }
 }
