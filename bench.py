@@ -579,6 +579,9 @@ def main():
     ap.add_argument("--difficulty", default="easy", choices=["easy", "hard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--no-streaming", action="store_true",
+                    help="skip the second timed loop (the same launches into 32 distinct buffers); for profiling the headline loop alone, "
+                         "so that a rocprofv3 average of k_step4 is the cache-resident launches only")
     ap.add_argument("--no-c4", action="store_true",
                     help="N > 1 only: skip the self-play PPO iteration (collector + fused update + gradient all-reduce) extra")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -683,7 +686,7 @@ def main():
     # The same launches in the STREAMING regime: the loop above re-writes ONE 118 MB observation buffer, which the 256 MiB Infinity
     # Cache keeps resident; a collector that keeps every step's observations writes distinct buffers.  Same kernel, same actions,
     # same protocol (repeats x steps launches, HIP events per group, median region), output slot = step % STREAM_SLOTS (3.8 GB).
-    STREAM_SLOTS = 32
+    STREAM_SLOTS = 1 if args.no_streaming else 32           # --no-streaming: the loop below degenerates to a short re-run of the headline loop
     from inversus_reinforcement_learning_amd.device_env import StepResult
     so = b._alloc_out((STREAM_SLOTS,), True, False, False, None)
     slots = [StepResult(**{k2: (getattr(so, k2)[j] if getattr(so, k2) is not None else None) for k2 in StepResult.__slots__})
@@ -692,7 +695,7 @@ def main():
     for t in range(max(args.warmup, STREAM_SLOTS)):
         sstep[t % STREAM_SLOTS](base + (t % total) * n)
     sregions = []
-    for _ in range(max(1, args.repeats)):
+    for _ in range(1 if args.no_streaming else max(1, args.repeats)):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
         fence()
         t0 = time.perf_counter()
@@ -762,7 +765,8 @@ def main():
                                    "*_streaming = the same launches into 32 distinct buffers (HBM writes)",
                          "kernel": "k_step4 (four envs per wavefront; csrc/inv_step4.h)" if b.step_kernel != "wave" else "k_step",
                          "kernel_ms": kern_ms_roof, "kernel_ms_per_rank": [round(x, 6) for x in kern_ms_ranks],
-                         "achieved_streaming": achieved_streaming, "frac_streaming": achieved_streaming / HBM_PEAK_GBS,
+                         "achieved_streaming": None if args.no_streaming else achieved_streaming,
+                         "frac_streaming": None if args.no_streaming else achieved_streaming / HBM_PEAK_GBS,
                          "kernel_ms_streaming": skern_ms_roof, "kernel_ms_streaming_per_rank": [round(x, 6) for x in skern_ms_ranks],
                          "value_streaming": world * n * args.steps / sdt, "ms_per_step_streaming": sdt / args.steps * 1e3,
                          "traffic_streaming": traffic_from_profiles(args.difficulty, "_streaming"),

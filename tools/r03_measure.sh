@@ -20,7 +20,7 @@ done
 unset CFG LAUNCHES
 if [ -z "$NO_BENCH" ]; then
   python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/kt.err; echo "kt bench rc=$?"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline --no-extras --no-streaming > $O/bench_under_rocprof.json 2> $O/kt.err; echo "kt bench rc=$?"
   find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats.csv; rm -rf $O/kt
   head -5 $O/bench_kernel_stats.csv | cut -c1-220; python3 -c "import json;d=json.load(open('$O/bench.json'));print(json.dumps({k:d[k] for k in ('value','ms_per_step','roofline')}, indent=1))"
 fi
