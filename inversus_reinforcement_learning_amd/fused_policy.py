@@ -125,6 +125,11 @@ class FusedPolicy:
     _banded_scratch = {}
 
     @classmethod
+    def release_banded_scratch(cls):
+        """Drop the cached scratch buffers (one per device and stream that ever ran the banded kernel)."""
+        cls._banded_scratch.clear()
+
+    @classmethod
     def _scratch_for(cls, device, nbytes):
         key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
         buf = cls._banded_scratch.get(key)

@@ -200,8 +200,7 @@ class _HeadsTrainFn(torch.autograd.Function):
         lib = L.load()
         feat, extra, h, a2 = ctx.saved_tensors
         P, B, dev = ctx.pixels, feat.shape[0], feat.device
-        small, dpre, dpre_t, da2 = ctx.mid_state
-        ctx.mid_state = None
+        small, dpre, dpre_t, da2 = ctx.mid_state                                        # (kept: lives as long as the context does)
         dwf = (dpre_t if dpre_t is not None else dpre.t()) @ feat                      # bf16 [512, 128 P], f32 accumulation over B
         gw1 = []
         with torch.cuda.device(dev):
