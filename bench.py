@@ -68,6 +68,20 @@ def host_threads():
     return aff, quota
 
 
+def gpu_identity(torch):
+    """Which GPU of the pool this was: the boards differ in sustained HBM write rate (5.7 vs 6.8 TB/s measured on two of them with the
+    same binary, profiles/r03_v2_c5_launch_series_*), which moves every figure whose footprint exceeds the Infinity Cache."""
+    try:
+        p = torch.cuda.get_device_properties(torch.cuda.current_device())
+        out = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count}
+        u = getattr(p, "uuid", None)
+        if u is not None:
+            out["uuid"] = str(u)
+        return out
+    except Exception as exc:                                              # pragma: no cover
+        return {"error": str(exc)}
+
+
 def thread_placement():
     """Where the OpenMP threads of the CPU baseline may run and where their memory comes from: the binding policy in force
     (none unless the environment sets one: threads float over the affinity mask under a CPU-time quota), the allowed CPUs /
@@ -753,7 +767,7 @@ def main():
             "config": {"workload": f"vs_dummy_{args.difficulty}: {n} envs/GPU, 15x10 grid, K=16, step+obs kernels only "
                                    "(Philox a1 stream, device dummy a2, reward/done, auto-reset, 12-ch obs)",
                        "envs_per_gpu": n, "sharding": f"env-shards x{world}, no data-path collective",
-                       "backend": (args.backend if use_dist else "none")},
+                       "backend": (args.backend if use_dist else "none"), "gpu": gpu_identity(torch)},
             "repeats": len(regions), "protocol": "median of the repeats' wall time (each = exactly `steps` vector steps, barrier + synchronize on both sides)",
             "ms_per_step_repeats": [round(r[0] / args.steps * 1e3, 6) for r in regions],
             # `frac` / `achieved` / `kernel_ms` describe the timed loop of `value`: ONE output buffer re-written every step, which the

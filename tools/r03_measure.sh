@@ -5,6 +5,7 @@
 set -o pipefail
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 O=gpurun_out/r03_m; mkdir -p $O
+rocm-smi --showuniqueid 2>/dev/null | grep "Unique ID:" | tee $O/gpu_unique_id.txt
 CFGS=${CFGS:-"easy hard selfplay_f32 selfplay_packed hard_packed c5 c5_packed easy_streaming hard_streaming rollout"}
 for c in $CFGS; do
   export CFG=$c LAUNCHES=200; [ $c = rollout ] && export LAUNCHES=8; [ ${c:0:2} = c5 ] && export LAUNCHES=60
