@@ -231,26 +231,28 @@ int64_t inv_policy_trunk_banded_scratch_bytes(int32_t height, int32_t width);
  * policies.py:91-99 at H = W = 32).  The forward additionally keeps, per sample, the four layers' pre-norm outputs z
  * (bf16 channels-last [N][H*W][32 | 64 | 128 | 128]) and the LayerNorm statistics (stats: f32 [N][4][2] = rstd, -mean*rstd);
  * the backward then runs layer by layer (l = 3 .. 0) over the whole batch:
- *   inv_policy_band_ln_bwd(l)       da_l (for l = 3: d loss / d feat) -> dy_l = da_l * [ReLU mask], dz_l (LayerNorm backward)
+ *   inv_policy_band_ln_bwd(l)       da_l (for l = 3: d loss / d feat) -> dz_l (LayerNorm + ReLU backward; the mask is recomputed from z_l),
+ *                                   optionally dy_l = da_l * [mask] and a_l = relu(LN(z_l)) (the `x` operand of inv_policy_band_wgrad(l + 1))
  *   inv_policy_band_conv_t(l)       l >= 1: da_{l-1} = convT(dz_l) (+ dz_3 for the residual); wt_packed =
  *                                   inv_policy_pack_conv(transposed = 1) of layer l, zero_bias: f32 zeros [128]
- *   inv_policy_band_act(l)          a_l = relu(LN(z_l)) as a tensor: the `x` operand of inv_policy_band_wgrad(l + 1)
+ *   inv_policy_band_act(l)          a_l = relu(LN(z_l)) as a tensor of its own (the training path takes it from inv_policy_band_ln_bwd)
  *   inv_policy_band_wgrad(l)        dW_l (f32 [Cout][9][CinP], ADDED) and dbias from x = a_{l-1} (l = 0: inv_policy_obs_to_x0_any) and dz_l
- *   inv_policy_band_param_grads(l)  per-slice partial sums [slices][2][H*W*C] of dy x^ and dy (LayerNorm weight / bias)
+ *   inv_policy_band_param_grads(l)  per-slice partial sums [slices][2][H*W*C] of dy x^ and dy (LayerNorm weight / bias), recomputed from da_l, z_l
  * All tensors bf16 channels-last [N][H*W][C] unless noted.  Built for 32 x 32. */
 typedef struct { void *z[4]; float *stats; } inv_policy_band_saved;
 int  inv_policy_trunk_banded_train_fwd(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, int32_t height, int32_t width,
                                        void *feat_bf16, const inv_policy_band_saved *saved, int32_t N, void *stream);
 int  inv_policy_band_ln_bwd(int32_t layer, int32_t height, int32_t width, const void *da_bf16, const void *z_bf16, const float *stats,
-                            const void *ln_packed, void *dy_bf16, void *dz_bf16, int32_t N, void *stream);
+                            const void *ln_packed, void *dy_bf16 /* may be NULL */, void *dz_bf16, void *act_bf16 /* may be NULL */,
+                            int32_t N, void *stream);
 int  inv_policy_band_conv_t(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,
                             const void *dz_bf16, void *da_below_bf16, int32_t N, void *stream);
 int  inv_policy_band_act(int32_t layer, int32_t height, int32_t width, const void *z_bf16, const float *stats, const void *ln_packed,
                          void *act_bf16, int32_t N, void *stream);
 int  inv_policy_band_wgrad(int32_t layer, int32_t height, int32_t width, const void *x_bf16, const void *dz_bf16, float *dw, float *dbias,
                            int32_t N, void *stream);
-int  inv_policy_band_param_grads(int32_t layer, const void *dy_bf16, const void *z_bf16, const float *stats, float *partial, int32_t slices,
-                                 int32_t elems_per_sample, int32_t N, void *stream);
+int  inv_policy_band_param_grads(int32_t layer, const void *da_bf16, const void *z_bf16, const float *stats, const void *ln_packed,
+                                 float *partial, int32_t slices, int32_t elems_per_sample, int32_t N, void *stream);
 int  inv_policy_obs_to_x0_any(const void *obs, int32_t obs_is_bits, int32_t pixels, void *x0_bf16, int32_t N, void *stream);
 int  inv_policy_trunk_banded(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, int32_t height, int32_t width,
                              void *feat_bf16, void *scratch, int64_t scratch_bytes, int32_t N, void *stream);

@@ -1558,22 +1558,28 @@ __global__ __launch_bounds__(256) void k_obs_to_x0(const void *__restrict__ obs,
 // Backward of the BANDED trunk (32 x 32 board, BASELINE config C5 with the fused update).  A sample's layer does not fit
 // LDS (262 KB of bf16 at 128 channels), so the backward runs LAYER BY LAYER over the whole batch, four kinds of kernels per
 // layer, all on the tensors the SAVE forward wrote (z, statistics) and on channels-last bf16 tensors [N][P][C]:
-//   k_band_ln_bwd      one workgroup per sample, two row passes:  dy = da * [x^ w + b > 0],  sums of dx^ = dy w and dx^ x^,
+//   k_band_ln_bwd      one workgroup per sample, two row passes over (da, z):  sums of dx^ = da [x^ w + b > 0] w and dx^ x^ (and the
+//                      activation a = relu(x^ w + b) written on the way: the x operand of the layer above's weight gradient),
 //                      then dz = rstd (dx^ - mean(dx^) - x^ mean(dx^ x^));  x^ = z rstd + shift is recomputed from the saved z
-//                      with the forward's own expressions, so the ReLU mask is the forward's
+//                      with the forward's own expressions, so the ReLU mask is the forward's; dy is never stored
 //   k_band_conv_t      da_below = convT(dz) (+ dz for the residual of layer 4): the banded implicit GEMM of the forward
 //                      (band_conv) on the transposed weights, input bands copied raw
-//   k_band_act         a = relu(LN(z)) as a tensor: the x operand of the weight-gradient kernel (the forward never stores it)
+//   k_band_act         a = relu(LN(z)) as a tensor of its own (kept for callers that want it; the training path gets it from k_band_ln_bwd)
 //   k_policy_wgrad<.., WgGeoBand>  weight / bias gradients, one band of 4 rows per work unit
-//   k_band_param_grads LayerNorm weight / bias gradients: per-slice partial sums of dy x^ and dy over the samples
+//   k_band_param_grads LayerNorm weight / bias gradients: per-slice partial sums of dy x^ and dy over the samples, dy and x^ recomputed
+//                      from (da, z)
 // HBM-bound passes and MFMA-bound GEMMs alternate as separate launches (no cross-layer fusion: 4.3 GB of activations per
 // 16 384-sample layer cannot stay on chip); what matters here is that C5 TRAINS through kernels of this library at all --
 // the alternative is torch autograd over the f32 module (measured in bench.py extras beside it).
 
+// dy is optional (tests): nothing downstream needs it as a tensor any more -- pass B and k_band_param_grads recompute the ReLU mask
+// from (da, z, LayerNorm parameters), which costs arithmetic in HBM-bound kernels and saves one tensor write and one read per layer.
+// act (layers 0..2): a = relu(x^ w + b), the x operand of the NEXT layer's weight-gradient kernel, written by pass A on the way
+// (it forms that expression anyway for the mask) instead of by a pass of its own over z.
 template <int C>
 __global__ __launch_bounds__(THREADS) void k_band_ln_bwd(const bf16 *__restrict__ da, const bf16 *__restrict__ z, const float *__restrict__ stats,
                                                           int layer, const void *__restrict__ ln_packed, bf16 *__restrict__ dy, bf16 *__restrict__ dz,
-                                                          int pixels, int N)
+                                                          bf16 *__restrict__ act, int pixels, int N)
 {
     __shared__ float red[2 * WAVES];
     constexpr int CH = 6;
@@ -1583,10 +1589,12 @@ __global__ __launch_bounds__(THREADS) void k_band_ln_bwd(const bf16 *__restrict_
         const float rstd = stats[(size_t)n * 8 + 2 * layer], shift = stats[(size_t)n * 8 + 2 * layer + 1];
         const bf16x8 *da8 = reinterpret_cast<const bf16x8 *>(da + (size_t)n * pixels * C);
         const bf16x8 *z8 = reinterpret_cast<const bf16x8 *>(z + (size_t)n * pixels * C);
-        bf16x8 *dy8 = reinterpret_cast<bf16x8 *>(dy + (size_t)n * pixels * C), *dz8 = reinterpret_cast<bf16x8 *>(dz + (size_t)n * pixels * C);
+        bf16x8 *dy8 = dy ? reinterpret_cast<bf16x8 *>(dy + (size_t)n * pixels * C) : nullptr;
+        bf16x8 *dz8 = reinterpret_cast<bf16x8 *>(dz + (size_t)n * pixels * C);
+        bf16x8 *act8 = act ? reinterpret_cast<bf16x8 *>(act + (size_t)n * pixels * C) : nullptr;
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll 1
-        for (int q0 = tid; q0 < items; q0 += CH * THREADS) {                 // pass A
+        for (int q0 = tid; q0 < items; q0 += CH * THREADS) {                 // pass A: the two sums (+ the activation tensor)
             bf16x8 a[CH], zz[CH];
             f16x8 l0[CH], l1[CH];
 #pragma unroll
@@ -1602,18 +1610,18 @@ __global__ __launch_bounds__(THREADS) void k_band_ln_bwd(const bf16 *__restrict_
             for (int j = 0; j < CH; ++j) {
                 const int q = q0 + j * THREADS;
                 if (q < items) {
-                    bf16x8 d;
+                    bf16x8 av;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float g = (float)(e < 4 ? l0[j][e] : l1[j][e - 4]), bb = (float)(e < 4 ? l0[j][4 + e] : l1[j][e]);
                         const float xh = fmaf((float)zz[j][e], rstd, shift);
-                        const bool on = fmaf(xh, g, bb) > 0.0f;                 // ln_relu8's expression: the forward's mask
-                        d[e] = on ? a[j][e] : (bf16)0.0f;
-                        const float dxh = (float)d[e] * g;
+                        const float pre = fmaf(xh, g, bb);                    // ln_relu8's expression: the forward's mask
+                        av[e] = (bf16)fmaxf(pre, 0.0f);
+                        const float dxh = pre > 0.0f ? (float)a[j][e] * g : 0.0f;
                         s1 += dxh;
                         s2 = fmaf(dxh, xh, s2);
                     }
-                    dy8[q] = d;
+                    if (act8) act8[q] = av;
                 }
             }
         }
@@ -1627,13 +1635,13 @@ __global__ __launch_bounds__(THREADS) void k_band_ln_bwd(const bf16 *__restrict_
         const float inv_cnt = 1.0f / ((float)C * (float)pixels);
         const float m1 = S1 * inv_cnt, m2 = S2 * inv_cnt;
 #pragma unroll 1
-        for (int q0 = tid; q0 < items; q0 += CH * THREADS) {                 // pass B: the same items, this thread's own dy
-            bf16x8 d[CH], zz[CH];
+        for (int q0 = tid; q0 < items; q0 += CH * THREADS) {                 // pass B: the same items again
+            bf16x8 a[CH], zz[CH];
             f16x8 l0[CH], l1[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int q = min(q0 + j * THREADS, items - 1);
-                d[j] = dy8[q]; zz[j] = z8[q];
+                a[j] = da8[q]; zz[j] = z8[q];
                 const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;
                 l0[j] = *reinterpret_cast<const f16x8 *>(lq);
                 l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
@@ -1643,14 +1651,16 @@ __global__ __launch_bounds__(THREADS) void k_band_ln_bwd(const bf16 *__restrict_
             for (int j = 0; j < CH; ++j) {
                 const int q = q0 + j * THREADS;
                 if (q < items) {
-                    bf16x8 o;
+                    bf16x8 o, d;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float g = (float)(e < 4 ? l0[j][e] : l1[j][e - 4]);
+                        const float g = (float)(e < 4 ? l0[j][e] : l1[j][e - 4]), bb = (float)(e < 4 ? l0[j][4 + e] : l1[j][e]);
                         const float xh = fmaf((float)zz[j][e], rstd, shift);
-                        o[e] = (bf16)(rstd * ((float)d[j][e] * g - m1 - xh * m2));
+                        d[e] = fmaf(xh, g, bb) > 0.0f ? a[j][e] : (bf16)0.0f;
+                        o[e] = (bf16)(rstd * ((float)d[e] * g - m1 - xh * m2));
                     }
                     dz8[q] = o;
+                    if (dy8) dy8[q] = d;
                 }
             }
         }
@@ -1755,26 +1765,37 @@ __global__ __launch_bounds__(THREADS) void k_band_act(const bf16 *__restrict__ z
     }
 }
 
-// LayerNorm weight / bias gradients of a banded layer: like k_policy_param_grads, with x^ = z rstd + shift recomputed from the
-// saved z and the per-sample statistics
-__global__ __launch_bounds__(256) void k_band_param_grads(const bf16 *__restrict__ dy, const bf16 *__restrict__ z, const float *__restrict__ stats,
-                                                           int layer, float *__restrict__ part, int E8, int N)
+// LayerNorm weight / bias gradients of a banded layer: like k_policy_param_grads, with everything recomputed from what the other
+// kernels read anyway -- x^ = z rstd + shift from the saved z and the per-sample statistics, dy = da * [x^ w + b > 0] from the
+// layer's incoming gradient (a thread owns the same 8 channels of one pixel for every sample, so its LayerNorm parameters are
+// loaded once)
+__global__ __launch_bounds__(256) void k_band_param_grads(const bf16 *__restrict__ da, const bf16 *__restrict__ z, const float *__restrict__ stats,
+                                                           int layer, const void *__restrict__ ln_packed, float *__restrict__ part, int E8, int N)
 {
     const int e8 = blockIdx.x * 256 + threadIdx.x;
     if (e8 >= E8) return;
-    float aw[8], ab[8];
+    float aw[8], ab[8], g[8], bb[8];
+    {
+        const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)e8 * 16;
+        const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) aw[j] = ab[j] = 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            aw[j] = ab[j] = 0.0f;
+            g[j] = (float)(j < 4 ? l0[j] : l1[j - 4]);
+            bb[j] = (float)(j < 4 ? l0[4 + j] : l1[j]);
+        }
+    }
     const size_t stride = (size_t)E8 * 8;
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
         const size_t o = (size_t)n * stride + (size_t)e8 * 8;
-        const bf16x8 d = *reinterpret_cast<const bf16x8 *>(dy + o);
+        const bf16x8 d = *reinterpret_cast<const bf16x8 *>(da + o);
         const bf16x8 zz = *reinterpret_cast<const bf16x8 *>(z + o);
         const float rstd = stats[(size_t)n * 8 + 2 * layer], shift = stats[(size_t)n * 8 + 2 * layer + 1];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float df = (float)d[j];
-            aw[j] = fmaf(df, fmaf((float)zz[j], rstd, shift), aw[j]);
+            const float xh = fmaf((float)zz[j], rstd, shift);
+            const float df = fmaf(xh, g[j], bb[j]) > 0.0f ? (float)d[j] : 0.0f;
+            aw[j] = fmaf(df, xh, aw[j]);
             ab[j] += df;
         }
     }
@@ -1945,16 +1966,17 @@ extern "C" int inv_policy_trunk_banded_train_fwd(const inv_policy_params *params
 }
 
 extern "C" int inv_policy_band_ln_bwd(int32_t layer, int32_t height, int32_t width, const void *da_bf16, const void *z_bf16, const float *stats,
-                                      const void *ln_packed, void *dy_bf16, void *dz_bf16, int32_t N, void *stream)
+                                      const void *ln_packed, void *dy_bf16, void *dz_bf16, void *act_bf16, int32_t N, void *stream)
 {
-    if (!da_bf16 || !z_bf16 || !stats || !ln_packed || !dy_bf16 || !dz_bf16 || N < 0 || layer < 0 || layer > 3)
-        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_ln_bwd: NULL tensor, N < 0 or layer outside 0..3");
+    if (!da_bf16 || !z_bf16 || !stats || !ln_packed || !dz_bf16 || N < 0 || layer < 0 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_ln_bwd: NULL tensor, N < 0 or layer outside 0..3 (dy and act may be NULL)");
     if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_ln_bwd: built for the 32 x 32 board");
     if (N == 0) return INV_OK;
     const int pixels = height * width, grid = N < 4 * inv_cu_count() ? N : 4 * inv_cu_count();
     using pol::bf16;
 #define INV_LNB(C_) hipLaunchKernelGGL((pol::k_band_ln_bwd<C_>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, reinterpret_cast<const bf16 *>(da_bf16), \
-        reinterpret_cast<const bf16 *>(z_bf16), stats, (int)layer, ln_packed, reinterpret_cast<bf16 *>(dy_bf16), reinterpret_cast<bf16 *>(dz_bf16), pixels, (int)N)
+        reinterpret_cast<const bf16 *>(z_bf16), stats, (int)layer, ln_packed, reinterpret_cast<bf16 *>(dy_bf16), reinterpret_cast<bf16 *>(dz_bf16), \
+        reinterpret_cast<bf16 *>(act_bf16), pixels, (int)N)
     if (kBandC[layer] == 32) INV_LNB(32); else if (kBandC[layer] == 64) INV_LNB(64); else INV_LNB(128);
 #undef INV_LNB
     return launch_status("inv_policy_band_ln_bwd");
@@ -2002,14 +2024,14 @@ extern "C" int inv_policy_band_act(int32_t layer, int32_t height, int32_t width,
     return launch_status("inv_policy_band_act");
 }
 
-extern "C" int inv_policy_band_param_grads(int32_t layer, const void *dy_bf16, const void *z_bf16, const float *stats, float *partial, int32_t slices,
-                                           int32_t elems_per_sample, int32_t N, void *stream)
+extern "C" int inv_policy_band_param_grads(int32_t layer, const void *da_bf16, const void *z_bf16, const float *stats, const void *ln_packed,
+                                           float *partial, int32_t slices, int32_t elems_per_sample, int32_t N, void *stream)
 {
-    if (!dy_bf16 || !z_bf16 || !stats || !partial || N < 0 || slices < 1 || elems_per_sample <= 0 || (elems_per_sample & 7) || layer < 0 || layer > 3)
+    if (!da_bf16 || !z_bf16 || !stats || !ln_packed || !partial || N < 0 || slices < 1 || elems_per_sample <= 0 || (elems_per_sample & 7) || layer < 0 || layer > 3)
         return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_param_grads: NULL tensor, N < 0, slices < 1, layer outside 0..3 or elems_per_sample not a positive multiple of 8");
     const int e8 = elems_per_sample / 8, bx = (e8 + 255) / 256;
-    hipLaunchKernelGGL(pol::k_band_param_grads, dim3(bx, slices), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const pol::bf16 *>(dy_bf16),
-                       reinterpret_cast<const pol::bf16 *>(z_bf16), stats, (int)layer, partial, e8, (int)N);
+    hipLaunchKernelGGL(pol::k_band_param_grads, dim3(bx, slices), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const pol::bf16 *>(da_bf16),
+                       reinterpret_cast<const pol::bf16 *>(z_bf16), stats, (int)layer, ln_packed, partial, e8, (int)N);
     return launch_status("inv_policy_band_param_grads");
 }
 

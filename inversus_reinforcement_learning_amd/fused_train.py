@@ -266,34 +266,41 @@ class _TrunkTrainBandedFn(torch.autograd.Function):
         def st():
             return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+        def wgrad(l, x, dz):
+            c, cin, cinp = _COUT[l], _CIN[l], _CINP[l]
+            dw = torch.zeros((c, 9, cinp), dtype=torch.float32, device=dev)
+            db = torch.zeros((c,), dtype=torch.float32, device=dev)
+            L.raise_for(lib.inv_policy_band_wgrad(l, hb, wb, _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), n, st()), lib)
+            grads[4 * l] = dw[:, :, :cin].reshape(c, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+            grads[4 * l + 1] = db
+
+        # l = 3 .. 0:  ln_bwd(l) [da_l, z_l -> dz_l, and a_l for the weight gradient of the layer above]  ->  wgrad(l + 1) [a_l, dz_{l+1}]
+        #              ->  LayerNorm sums(l) [da_l, z_l]  ->  conv_t(l) [dz_l -> da_{l-1}];  finally wgrad(0) [x0, dz_0]
         with torch.cuda.device(dev):
+            dz_above = None
             for l in (3, 2, 1, 0):
                 c = _COUT[l]
-                dy, dz = torch.empty_like(z[l]), torch.empty_like(z[l])
-                L.raise_for(lib.inv_policy_band_ln_bwd(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(dy), _ptr(dz), n, st()), lib)
+                dz = torch.empty_like(z[l])
+                act = torch.empty_like(z[l]) if l < 3 else None
+                L.raise_for(lib.inv_policy_band_ln_bwd(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), None, _ptr(dz),
+                                                       _ptr(act) if act is not None else None, n, st()), lib)
+                if l < 3:
+                    wgrad(l + 1, act, dz_above)
+                    del act, dz_above
                 slices = max(1, min(n, _RED_SLICES))
                 part = torch.empty((slices, 2, pix, c), dtype=torch.float32, device=dev)
-                L.raise_for(lib.inv_policy_band_param_grads(l, _ptr(dy), _ptr(z[l]), _ptr(stats), _ptr(part), slices, pix * c, n, st()), lib)
+                L.raise_for(lib.inv_policy_band_param_grads(l, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(part), slices, pix * c, n, st()), lib)
                 red = part.sum(dim=0)
                 grads[4 * l + 2], grads[4 * l + 3] = red[0].t().reshape(c, hb, wb), red[1].t().reshape(c, hb, wb)
-                del dy, part
-                da = None
+                del part
                 if l >= 1:
                     wt = pack_conv(ws[l], _COUT[l], transposed=True)
                     da = torch.empty((n, pix, _COUT[l - 1]), dtype=torch.bfloat16, device=dev)
                     L.raise_for(lib.inv_policy_band_conv_t(l, hb, wb, _ptr(wt), _ptr(zero_bias), _ptr(dz), _ptr(da), n, st()), lib)
-                    x = torch.empty((n, pix, _COUT[l - 1]), dtype=torch.bfloat16, device=dev)
-                    L.raise_for(lib.inv_policy_band_act(l - 1, hb, wb, _ptr(z[l - 1]), _ptr(stats), _ptr(lns[l - 1]), _ptr(x), n, st()), lib)
-                else:
-                    x = torch.empty((n, pix, 16), dtype=torch.bfloat16, device=dev)
-                    L.raise_for(lib.inv_policy_obs_to_x0_any(_ptr(obs), 1 if ctx.bits else 0, pix, _ptr(x), n, st()), lib)
-                cin, cinp = _CIN[l], _CINP[l]
-                dw = torch.zeros((c, 9, cinp), dtype=torch.float32, device=dev)
-                db = torch.zeros((c,), dtype=torch.float32, device=dev)
-                L.raise_for(lib.inv_policy_band_wgrad(l, hb, wb, _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), n, st()), lib)
-                grads[4 * l] = dw[:, :, :cin].reshape(c, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
-                grads[4 * l + 1] = db
-                del dz, x
+                dz_above = dz
+            x0 = torch.empty((n, pix, 16), dtype=torch.bfloat16, device=dev)
+            L.raise_for(lib.inv_policy_obs_to_x0_any(_ptr(obs), 1 if ctx.bits else 0, pix, _ptr(x0), n, st()), lib)
+            wgrad(0, x0, dz_above)
         return (None, *grads)
 
 

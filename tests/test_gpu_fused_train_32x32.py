@@ -116,8 +116,11 @@ def test_band_ln_bwd_act_and_param_grads_match_autograd(layer):
     rstd = 1.0 / torch.sqrt(zf.var(dim=(1, 2), unbiased=False) + 1e-5)
     stats = torch.zeros(n, 4, 2, device="cuda")
     stats[:, layer, 0], stats[:, layer, 1] = rstd, -mean * rstd
-    dy, dz = torch.empty_like(z), torch.empty_like(z)
-    L.raise_for(lib.inv_policy_band_ln_bwd(layer, H, W, _p(da), _p(z), _p(stats), _p(ln), _p(dy), _p(dz), n, _st()), lib)
+    dy, dz, act_k = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+    L.raise_for(lib.inv_policy_band_ln_bwd(layer, H, W, _p(da), _p(z), _p(stats), _p(ln), _p(dy), _p(dz), _p(act_k), n, _st()), lib)
+    dz2 = torch.empty_like(z)                                              # dy and act are optional outputs: same dz without them
+    L.raise_for(lib.inv_policy_band_ln_bwd(layer, H, W, _p(da), _p(z), _p(stats), _p(ln), None, _p(dz2), None, n, _st()), lib)
+    assert torch.equal(dz, dz2)
     # torch: a = relu(LN(z) * w + b) on the same z, gradient da
     zt = zf.clone().requires_grad_(True)
     wcl, bcl = gw.reshape(c, P).t().contiguous().requires_grad_(True), gb.reshape(c, P).t().contiguous().requires_grad_(True)   # [P][c]
@@ -127,12 +130,13 @@ def test_band_ln_bwd_act_and_param_grads_match_autograd(layer):
     assert rel(dz, zt.grad) < 8e-3, rel(dz, zt.grad)
     mask = (xh * wcl + bcl) > 0
     assert rel(dy, da.float() * mask) < 2e-3
+    assert rel(act_k, a.detach()) < 5e-3                                      # the activation pass A writes on the way
     if layer < 3:
         act = torch.empty_like(z)
         L.raise_for(lib.inv_policy_band_act(layer, H, W, _p(z), _p(stats), _p(ln), _p(act), n, _st()), lib)
-        assert rel(act, a.detach()) < 5e-3
+        assert torch.equal(act, act_k)                                       # == the stand-alone activation kernel, bit for bit
     part = torch.empty(4, 2, P, c, device="cuda")
-    L.raise_for(lib.inv_policy_band_param_grads(layer, _p(dy), _p(z), _p(stats), _p(part), 4, P * c, n, _st()), lib)
+    L.raise_for(lib.inv_policy_band_param_grads(layer, _p(da), _p(z), _p(stats), _p(ln), _p(part), 4, P * c, n, _st()), lib)
     red = part.sum(0)
     assert rel(red[0], wcl.grad) < 3e-3 and rel(red[1], bcl.grad) < 3e-3, (rel(red[0], wcl.grad), rel(red[1], bcl.grad))
 
