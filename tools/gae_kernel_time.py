@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from inversus_reinforcement_learning_amd import _lib as L
 lib = L.load()
 res = {}
-for T, n in ((128, 16384), (128, 131072), (512, 4096), (128, 4096)):
+cfgs = ((128, 16384), (128, 131072), (512, 4096), (128, 4096))
+if os.environ.get("GAE_CFG"):                                          # e.g. GAE_CFG=128,16384: one configuration (for a rocprofv3 row of its own)
+    cfgs = (tuple(int(x) for x in os.environ["GAE_CFG"].split(",")),)
+for T, n in cfgs:
     r = torch.randn(T, n, device="cuda"); v = torch.randn(T, n, device="cuda"); d = (torch.rand(T, n, device="cuda") < 0.03).to(torch.uint8)
     adv, ret = torch.empty_like(r), torch.empty_like(r)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
