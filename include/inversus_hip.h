@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define INV_ABI_VERSION 5
+#define INV_ABI_VERSION 6
 
 typedef enum {
     INV_OK = 0,
@@ -309,10 +309,29 @@ int  inv_policy_pack_conv(const float *w, int32_t cout, int32_t cin, int32_t cin
 int  inv_policy_pack_ln(const float *weight, const float *bias, int32_t cout, int32_t pixels, void *out_f16, void *stream);
 int  inv_policy_obs_to_x0(const void *obs, int32_t obs_is_bits, void *x0_bf16, int32_t N, void *stream);
 
+/* ---- the first Linear of the policy heads ("fused heads GEMM [B x 19 204] . [19 204 x 512]") ------------
+ * Reference: inversus_rl/policies.py:60-75 (fc_actor[0], fc_critic[0] = Linear(128 P + 4, 256)), :102-106 (features ++ extra), and
+ * their autograd derivatives in ppo_agent.py:211-232.  bf16 operands, f32 accumulation, hand-written MFMA kernels (csrc/inv_fc1.hip);
+ * feature index = p * 128 + c (the trunk kernels' channels-last order).  The 4 extra columns / bias / ReLU are inv_heads_fwd's.
+ *   inv_fc1_fwd    pre = feat [B][K] @ wf [nout][K]^T, K = 128 P, nout = 256 nheads, written as inv_fc1_fwd_slabs(B, nout, K) f32
+ *                  split-K partial sums pre_slabs [slabs][B][nout] (inv_heads_fwd adds them in slab order).
+ *   inv_fc1_dfeat  dfeat bf16 [B][nfeat] = dpre [B][nhid] @ wft [nfeat][nhid]^T   (wft = inv_transpose_bf16(wf))
+ *   inv_fc1_dw     weight gradient in the MODULE's layout: grad_w_actor / grad_w_critic f32 [256][128 P + 4] (overwritten), column
+ *                  c * P + p (nn.Flatten's order) = sum_b dpre_t[j][b] feat[b][p * 128 + c], last 4 columns = dwe [nhid][4].
+ *                  dpre_t bf16 [nhid][ld], ld = B rounded up to a multiple of 64, columns B .. ld - 1 ZERO (inv_heads_bwd writes it).
+ *                  workspace: inv_fc1_dw_workspace_bytes(B, nhid, 128 P) bytes (stream-K segment sums).  nhid = 512 (256: actor only,
+ *                  grad_w_critic unused). */
+int32_t inv_fc1_fwd_slabs(int32_t B, int32_t nout, int32_t K);
+int  inv_fc1_fwd(const void *feat_bf16, const void *wf_bf16, int32_t B, int32_t nout, int32_t K, float *pre_slabs, void *stream);
+int  inv_fc1_dfeat(const void *dpre_bf16, const void *wft_bf16, int32_t B, int32_t nhid, int32_t nfeat, void *dfeat_bf16, void *stream);
+int64_t inv_fc1_dw_workspace_bytes(int32_t B, int32_t nhid, int32_t nfeat);
+int  inv_fc1_dw(const void *dpre_t_bf16, const void *feat_bf16, const float *dwe, int32_t B, int32_t nhid, int32_t pixels,
+                float *grad_w_actor, float *grad_w_critic, void *workspace, void *stream);
+
 /* ---- the policy heads after their first Linear ------------------------------------------
  * Reference: inversus_rl/policies.py:60-75 (fc_actor, fc_critic = Linear(19204, 256) ReLU Linear(256, 128) ReLU Linear(128, 13 | 1))
- * and :102-106.  The first Linear's big product  pre = features @ W1[:, :128 P]^T  (bf16 [B][256 nheads], columns 0..255 actor,
- * 256..511 critic) is the caller's GEMM; these entry points are everything after it, forward and backward, one kernel each:
+ * and :102-106.  The first Linear's big product  pre = features @ W1[:, :128 P]^T  (f32 [B][256 nheads], columns 0..255 actor,
+ * 256..511 critic) is inv_fc1_fwd's; these entry points are everything after it, forward and backward, one kernel each:
  *     h = relu(pre + extra W1[:, 128 P:]^T + b1)      a2 = relu(W2 h + b2)      logits | value = W3 a2 + b3
  * h and a2 are rounded to bf16, W2 / W3 are bf16 MFMA operands, accumulation / biases / the extra columns are f32.
  * Packed operands (inv_heads_pack): MFMA A fragments of a [rows x cols] matrix padded to [mpad x kpad] (multiples of 16 / 32),
@@ -334,26 +353,27 @@ typedef struct { const float *src; void *dst; int32_t rows, cols, ld, transposed
 typedef struct { inv_heads_pack_item item[INV_HEADS_PACK_MAX]; } inv_heads_pack_list;
 int  inv_heads_pack(const inv_heads_pack_list *list, int32_t count, void *stream);                  /* one launch for `count` matrices */
 /* First Linear, `rows` output rows: w f32 [rows][128 P + 4] (feature index c * P + p, nn.Flatten's order) -> wf bf16 [rows][128 P]
- * in the trunk kernels' channels-last order p * 128 + c, and we f32 [rows][4]; and the gradient's way back (dwf bf16, dwe f32 ->
- * grad_w f32 [rows][128 P + 4], overwritten). */
+ * in the trunk kernels' channels-last order p * 128 + c, and we f32 [rows][4] (the way back is inv_fc1_dw's epilogue). */
 int  inv_heads_pack_fc1(const float *w, int32_t rows, int32_t pixels, void *wf_bf16, float *we, void *stream);
-int  inv_heads_unpack_fc1_grad(const void *dwf_bf16, const float *dwe, int32_t rows, int32_t pixels, float *grad_w, void *stream);
-/* bf16 [rows][cols] -> [cols][rows]: K-contiguous copies of GEMM operands (the library's NN / NT kernels are the fast ones) */
+/* bf16 [rows][cols] -> [cols][rows]: the K-contiguous copy of the first Linear's weights that inv_fc1_dfeat reads */
 int  inv_transpose_bf16(const void *in_bf16, int32_t rows, int32_t cols, void *out_bf16, void *stream);
-/* Forward.  nheads = 2: actor and critic (pre [B][512]); nheads = 1: actor only (pre [B][256], value may be NULL) -- the frozen
- * self-play opponent.  logits f32 [B][13], value f32 [B].  h_save bf16 [B][256 nheads] and a2_save bf16 [B][128 nheads]: both or
- * neither; what inv_heads_bwd needs.  The result for a sample does not depend on B or on its position in the batch. */
-int  inv_heads_fwd(const inv_heads_params *params, const void *pre_bf16, const float *extra, float *logits, float *value,
+/* Forward.  pre_slabs f32 [nslabs][B][256 nheads] = inv_fc1_fwd's output (nslabs >= 1).  nheads = 2: actor and critic; nheads = 1:
+ * actor only (value may be NULL) -- the frozen self-play opponent.  logits f32 [B][13], value f32 [B].  h_save bf16 [B][256 nheads]
+ * and a2_save bf16 [B][128 nheads]: both or neither; what inv_heads_bwd needs.  For a fixed slab count the result for a sample does
+ * not depend on B or on its position in the batch. */
+int  inv_heads_fwd(const inv_heads_params *params, const float *pre_slabs, int32_t nslabs, const float *extra, float *logits, float *value,
                    void *h_save, void *a2_save, int32_t nheads, int32_t B, void *stream);
 /* Backward (both heads).  In: dlogits f32 [B][13], dvalue f32 [B], the saved h / a2, extra f32 [B][4].  Out: dpre bf16 [B][512]
- * (= d loss / d pre, the operand of the first Linear's two backward GEMMs), optionally (non-NULL, B % 8 == 0) its transpose
- * dpre_t bf16 [512][B] for the weight-gradient product, da2 bf16 [B][256] (with h: the operands of
- * dW2[h] = da2[:, 128 h:128 h + 128]^T h[:, 256 h:256 h + 256]), and ADDED into the f32 buffers of `grads` (zero them first):
+ * (= d loss / d pre, the operand of inv_fc1_dfeat), optionally (non-NULL) its transpose dpre_t bf16 [512][dpre_t_ld] (dpre_t_ld >= B, a
+ * multiple of 8; inv_fc1_dw wants B rounded up to 64 with the tail zeroed by the caller), da2 bf16 [B][256] (with h: the operands
+ * of inv_heads_dw2), and ADDED into the f32 buffers of `grads` (zero them first):
  * db1 [512], dwe [512][4], db2[h] [128], dw3[h] [13 | 1][128], db3[h] [13 | 1]. */
 typedef struct { float *db1, *dwe, *db2[2], *dw3[2], *db3[2]; } inv_heads_grads;
 int  inv_heads_bwd(const inv_heads_params *params, const float *dlogits, const float *dvalue, const void *h, const void *a2,
-                   const float *extra, void *dpre_bf16, void *dpre_t_bf16, void *da2_bf16, const inv_heads_grads *grads, int32_t B,
-                   void *stream);
+                   const float *extra, void *dpre_bf16, void *dpre_t_bf16, int32_t dpre_t_ld, void *da2_bf16, const inv_heads_grads *grads,
+                   int32_t B, void *stream);
+/* dW2[h] f32 [128][256] += da2[:, 128 h : 128 h + 128]^T h_saved[:, 256 h : 256 h + 256] (zero the two buffers first). */
+int  inv_heads_dw2(const void *da2_bf16, const void *h_bf16, int32_t B, float *dw2_actor, float *dw2_critic, void *stream);
 
 /* ---- the scalar tail of the PPO update ------------------------------------------------------
  * inv_ppo_loss: forward AND backward of the reference's minibatch loss (inversus_rl/ppo_agent.py:211-224)

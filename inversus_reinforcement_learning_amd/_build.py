@@ -8,7 +8,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libinversus_hip.so")
 SOURCES = [os.path.join(CSRC, "inv_api.hip"), os.path.join(CSRC, "inv_gae.hip"), os.path.join(CSRC, "inv_policy.hip"),
-           os.path.join(CSRC, "inv_optim.hip"), os.path.join(CSRC, "inv_heads.hip")]
+           os.path.join(CSRC, "inv_optim.hip"), os.path.join(CSRC, "inv_heads.hip"), os.path.join(CSRC, "inv_fc1.hip")]
 HEADERS = [os.path.join(CSRC, "inv_device.h"), os.path.join(CSRC, "inv_step4.h"), os.path.join(CSRC, "inv_internal.h"), os.path.join(ROOT, "include", "inversus_hip.h")]
 
 # -ffp-contract=off: the reward is an f64 sum in the reference's order and GAE is strict f32

@@ -143,9 +143,14 @@ SIGNATURES = {
     "inv_policy_obs_to_x0_any": (C.c_int, [_V, C.c_int32, C.c_int32, _V, C.c_int32, _V]),
     "inv_heads_pack": (C.c_int, [P(InvHeadsPackList), C.c_int32, _V]),
     "inv_heads_pack_fc1": (C.c_int, [_V, C.c_int32, C.c_int32, _V, _V, _V]),
-    "inv_heads_unpack_fc1_grad": (C.c_int, [_V, _V, C.c_int32, C.c_int32, _V, _V]),
-    "inv_heads_fwd": (C.c_int, [P(InvHeadsParams), _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, _V]),
-    "inv_heads_bwd": (C.c_int, [P(InvHeadsParams), _V, _V, _V, _V, _V, _V, _V, _V, P(InvHeadsGrads), C.c_int32, _V]),
+    "inv_heads_fwd": (C.c_int, [P(InvHeadsParams), _V, C.c_int32, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, _V]),
+    "inv_heads_bwd": (C.c_int, [P(InvHeadsParams), _V, _V, _V, _V, _V, _V, _V, C.c_int32, _V, P(InvHeadsGrads), C.c_int32, _V]),
+    "inv_heads_dw2": (C.c_int, [_V, _V, C.c_int32, _V, _V, _V]),
+    "inv_fc1_fwd_slabs": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "inv_fc1_fwd": (C.c_int, [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V]),
+    "inv_fc1_dfeat": (C.c_int, [_V, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V]),
+    "inv_fc1_dw_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "inv_fc1_dw": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V]),
     "inv_transpose_bf16": (C.c_int, [_V, C.c_int32, C.c_int32, _V, _V]),
     "inv_ppo_loss_blocks": (C.c_int32, [C.c_int32]),
     "inv_ppo_loss": (C.c_int, [_V, _V, _V, _V, _V, _V, C.c_int32, C.c_float, C.c_float, C.c_float, _V, _V, _V, _V]),

@@ -1,0 +1,610 @@
+// inv_fc1.hip -- the first Linear of the two policy heads as kernels of this library ("fused heads GEMM
+// [B x 19 204] . [19 204 x 512]").  Reference: inversus_rl/policies.py:60-75 (fc_actor[0] / fc_critic[0] = Linear(128 P + 4, 256))
+// and :102-106 (features ++ extra -> heads), differentiated by autograd in ppo_agent.py:211-232.  Three products, all bf16
+// operands with f32 accumulation on v_mfma_f32_16x16x32_bf16:
+//   inv_fc1_fwd     pre[b][j]   = sum_k feat[b][k] wf[j][k]          K = 128 P (19 200 | 131 072), j < 256 nheads      (rollouts + update)
+//   inv_fc1_dfeat   dfeat[b][k] = sum_j dpre[b][j] wft[k][j]         K = 512: what the trunk's backward waits for
+//   inv_fc1_dw      dwf[j][k]   = sum_b dpre_t[j][b] feat[b][k]      K = B: the weight gradient, straight into the module's layout
+// (the 4 extra-feature columns, the bias and the ReLU of the layer are inv_heads_fwd's first-layer epilogue).
+//
+// One kernel core for all three: a 256 x 256 output tile per 512-thread workgroup (8 waves = 2 x 4, a wave owns 128 x 64 = 8 x 4 MFMA
+// tiles = 128 accumulator registers), K-tiles of 64 streamed HBM / L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no
+// VGPR round trip) into two 64-KB buffers of four 16-KB half-tiles (X rows 0-127 / 128-255, W rows 0-127 / 128-255).  A K-tile is
+// four PHASES (one quadrant of the wave's tile each: 16 MFMAs); a phase = [LDS fragment reads + one half-tile's DMA requests]
+// s_barrier [16 MFMAs] s_barrier, and waves 4-7 run ONE BARRIER BEHIND waves 0-3, so on every SIMD one wave computes while its
+// partner loads (the two waves of a SIMD are w and w + 4).  DMA requests stay in flight across the barriers: the only vmcnt wait
+// of a K-tile sits in its last phase and leaves the newest half-tile outstanding.  Hazards (segments = barrier intervals; group 0
+// loads in even segments, group 1 in odd ones):
+//   write-after-read   a half-tile slot is re-filled no earlier than two segments after the last ds_read of its old content
+//                      (the reader's lgkmcnt wait and the next barrier lie in between);
+//   read-after-write   every wave waits for its own requests (counted vmcnt) in the phase BEFORE the first read, and a barrier
+//                      separates that wait from every reader.
+// LDS image of a half-tile [128 rows][64 k]: 1-KB pieces of 8 rows x 128 B (one DMA wave-instruction = one piece = 8 full
+// 128-byte lines of the operand), the 16-byte chunk index XORed with (row >> 1) & 7 on the SOURCE address (the DMA writes LDS
+// lane-linearly) and on the fragment reads: every ds_read_b128 quarter-wave touches 16 different bank groups.
+// The weight gradient's `feat` operand is K-STRIDED (its rows are the contraction index): it is staged as pieces of 8 k-rows x
+// 64 columns and read with ds_read_b64_tr_b16 (the transposing LDS read), 32-byte column blocks XORed so that the eight rows of a
+// half-wave fall into eight different bank groups.
+// Work distribution: forward = split-K so that 256 workgroups exist (B = 16 384: 64 x 2 tiles x 2 K-halves; partial sums go to f32
+// slabs that inv_heads_fwd adds -- one rounding less than a bf16 `pre`); dfeat = persistent workgroups walking 4 800 tiles with the
+// DMA stream running across tile boundaries; dw = stream-K (150 tiles x 256 K-tiles dealt as 150 K-tiles per workgroup, f32
+// segment slabs summed and transposed into the module's [j][c P + p] order by k_fc1_dw_reduce).
+// The result for a sample does not depend on the batch or on its position in it (fixed K order per output element).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/inversus_hip.h"
+#include "inv_internal.h"
+
+namespace fc1 {
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+constexpr int THREADS = 512;
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF = 16384;              // bytes of a half-tile: 128 rows x 64 k (or 64 k-rows x 128 columns) of bf16
+constexpr int BUF = 4 * HALF;            // X0 X1 W0 W1
+constexpr int LDS_BYTES = 2 * BUF;       // 128 KiB of the CU's 160
+
+enum { MODE_FWD = 0, MODE_DFEAT = 1, MODE_DW = 2 };
+
+struct Args {
+    const bf16 *X, *W;                   // X: the operand whose rows land on MFMA lanes (output rows), W: rows on registers (output columns)
+    void *out;
+    int M, N, K;                         // valid rows of X, rows (MODE_DW: columns) of W, contraction length
+    int ldx, ldw, ldo;                   // leading dimensions in elements
+    int tiles_m, tiles_n, split, ktiles; // ktiles = K / 64
+    int total;                           // work items (FWD: tiles x split; DFEAT: tiles) or K-tiles per workgroup (DW)
+};
+
+struct Item { int m0, n0, kt0, kt1, aux; };   // K-tile range [kt0, kt1); aux: slab (FWD) / segment (DW)
+
+__device__ __forceinline__ int xcd_remap(int b, int total)
+{
+    // blocks b and b + 8 share an XCD (observed dispatch; speed only): give each XCD a contiguous range of work ids
+    return (total & 7) == 0 ? (b & 7) * (total >> 3) + (b >> 3) : b;
+}
+
+template <int MODE>
+__device__ __forceinline__ Item get_item(const Args &a, int seq)
+{
+    Item it;
+    it.m0 = it.n0 = it.kt0 = it.kt1 = it.aux = 0;
+    if (MODE == MODE_FWD) {
+        if (seq == 0) {
+            // n fastest (the two column tiles of an X slab run side by side on one XCD), K-split slowest (an XCD streams one K range of W)
+            const int L = xcd_remap((int)blockIdx.x, a.total);
+            const int n = L % a.tiles_n, r = L / a.tiles_n, m = r % a.tiles_m, s = r / a.tiles_m;
+            it.m0 = m * BM; it.n0 = n * BN; it.aux = s;
+            it.kt0 = (int)((long long)a.ktiles * s / a.split);
+            it.kt1 = (int)((long long)a.ktiles * (s + 1) / a.split);
+        }
+    } else if (MODE == MODE_DFEAT) {
+        // Persistent workgroups.  Each XCD (the blocks b with equal b & 7: observed dispatch, speed only) walks ONE eighth of the
+        // tile sequence  [column group x][row tile m][column tile n of group x]  (groups = the column tiles cut in eight), so its
+        // L2 holds its own ~10 column tiles of W (2.5 MB) and streams the rows of X once
+        const int nb = (int)gridDim.x;
+        if ((a.total & 7) == 0 && (nb & 7) == 0) {
+            const int per = a.total >> 3, x = (int)blockIdx.x & 7, G = x * per + ((int)blockIdx.x >> 3) + (nb >> 3) * seq;
+            if (G < (x + 1) * per) {
+                int g = 0;                                                               // group of G: offsets tiles_m * floor(tiles_n * g / 8)
+                while (g < 7 && a.tiles_m * ((a.tiles_n * (g + 1)) >> 3) <= G) ++g;
+                const int n_lo = (a.tiles_n * g) >> 3, n_cnt = ((a.tiles_n * (g + 1)) >> 3) - n_lo, r = G - a.tiles_m * n_lo;
+                it.m0 = (r / n_cnt) * BM; it.n0 = (n_lo + r % n_cnt) * BN; it.kt0 = 0; it.kt1 = a.ktiles;
+            }
+        } else {
+            const int L = (int)blockIdx.x + nb * seq;
+            if (L < a.total) {
+                const int n = L % a.tiles_n, m = L / a.tiles_n;
+                it.m0 = m * BM; it.n0 = n * BN; it.kt0 = 0; it.kt1 = a.ktiles;
+            }
+        }
+    } else {
+        // stream-K over UNITS u = (column tile n, K-tile) of the W operand (feat: streamed from HBM once); the tiles_m row tiles of
+        // a unit run in lockstep on tiles_m workgroups of one XCD (blocks b, b + 8, ...), so a unit's W K-tile is fetched once and
+        // shared through that XCD's L2.  Stream q = chunk of a.total consecutive units; it crosses column tiles (segments).
+        const int nb = (int)gridDim.x, nq = nb / a.tiles_m;
+        int m, q;
+        if ((nb & 7) == 0 && ((nb >> 3) % a.tiles_m) == 0) {
+            const int s = (int)blockIdx.x >> 3;
+            m = s % a.tiles_m;
+            q = ((int)blockIdx.x & 7) * ((nb >> 3) / a.tiles_m) + s / a.tiles_m;
+        } else {
+            m = (int)blockIdx.x % a.tiles_m;
+            q = (int)blockIdx.x / a.tiles_m;
+        }
+        (void)nq;
+        const long long lo = (long long)q * a.total, hi = lo + a.total, all = (long long)a.tiles_n * a.ktiles;
+        const int n = (int)(lo / a.ktiles) + seq;
+        const long long b0 = (long long)n * a.ktiles, b1 = b0 + a.ktiles;
+        const long long e1 = hi < b1 ? hi : b1;
+        const long long s0 = lo > b0 ? lo : b0, s1 = e1 < all ? e1 : all;
+        if (s0 < s1) {
+            it.m0 = m * BM; it.n0 = n * BN; it.kt0 = (int)(s0 - b0); it.kt1 = (int)(s1 - b0);
+            it.aux = (q * a.split + seq) * a.tiles_m + m;                       // a.split = segments a stream can touch
+        }
+    }
+    return it;
+}
+
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_frag(const lds_byte *lo_p, const lds_byte *hi_p)
+{
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lo_p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(hi_p));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// A producer cursor: the K-tile whose half-tiles are requested next, with the buffer descriptors of its tile rows.
+template <int MODE>
+struct Cursor {
+    Item it;
+    int seq, kt;
+    bool valid;
+    __amdgpu_buffer_rsrc_t rx, rw;
+
+    // descriptor from wave-uniform values, made PROVABLY uniform (readfirstlane): otherwise hipcc wraps every buffer_load in a
+    // waterfall loop
+    static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, long long bytes)
+    {
+        const uint64_t b = (uint64_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes)));
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)n, 0x00020000);
+    }
+    __device__ __forceinline__ void bind(const Args &a)
+    {
+        valid = it.kt0 < it.kt1;
+        // X rows past M read as zeros (the descriptor's range check); W rows always exist
+        int xrows = a.M - it.m0;
+        xrows = xrows < 0 ? 0 : (xrows > BM ? BM : xrows);
+        rx = make_rsrc(a.X + (size_t)it.m0 * a.ldx, valid ? (long long)xrows * a.ldx * 2 : 0);
+        if (MODE == MODE_DW) bind_w_rows(a);
+        else rw = make_rsrc(a.W + (size_t)it.n0 * a.ldw, valid ? (long long)BN * a.ldw * 2 : 0);
+    }
+    // MODE_DW: W = feat [K rows][N]; the descriptor starts at K-tile `kt`'s first row and ends behind the LAST VALID row's 256
+    // columns, so that rows past K (= B) fail the range check on the per-lane offset alone and read as zeros (the contraction
+    // length is padded to a multiple of 64 on the X side)
+    __device__ __forceinline__ void bind_w_rows(const Args &a)
+    {
+        const long long left = (long long)a.K - (long long)kt * BK;                 // rows of this K-tile onwards
+        rw = make_rsrc(a.W + it.n0 + (size_t)kt * BK * a.ldw, valid && left > 0 ? ((left - 1) * a.ldw + BN) * 2 : 0);
+    }
+    __device__ __forceinline__ void start(const Args &a)
+    {
+        seq = 0;
+        it = get_item<MODE>(a, 0);
+        kt = it.kt0;
+        bind(a);
+    }
+    __device__ __forceinline__ void advance(const Args &a)
+    {
+        if (!valid) return;
+        if (++kt == it.kt1) {
+            it = get_item<MODE>(a, ++seq);
+            kt = it.kt0;
+            bind(a);
+        } else if (MODE == MODE_DW) {
+            bind_w_rows(a);
+        }
+    }
+};
+
+template <int MODE, bool STAGGER>
+__global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (it cannot instantiate a body built on buffer descriptors)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+    lds_byte *const lds = (lds_byte *)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
+    const int wr = wave >> 2, wc = wave & 3;
+    constexpr bool WT = MODE == MODE_DW;                 // W operand K-strided: transposing reads
+
+    // ---- staging: piece pc = 8 j + wave (j = 0, 1) of a half-tile
+    //   K-contiguous operand: piece = rows 8 pc .. 8 pc + 7, this lane: row 8 pc + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
+    //   K-strided operand (WT): the half-tile is [64 k-rows][128 columns]; piece = (k-block kb = pc >> 1 of 8 rows, column half pc & 1):
+    //   lane: k-row 8 kb + (lane >> 3), 16-byte chunk (lane & 7) ^ (2 * f), f = ((kb & 1) << 1) | ((row >> 1) & 1)  (32-byte blocks swap)
+    uint32_t vx[2], vw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pc = 8 * j + wave, r = 8 * pc + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        vx[j] = (uint32_t)r * (uint32_t)a.ldx * 2u + (uint32_t)c * 16u;
+        if (WT) {
+            const int kb = pc >> 1, ch = pc & 1, kr = 8 * kb + (lane >> 3), f = ((kb & 1) << 1) | ((kr >> 1) & 1);
+            vw[j] = (uint32_t)kr * (uint32_t)a.ldw * 2u + (uint32_t)ch * 128u + (uint32_t)((lane & 7) ^ (2 * f)) * 16u;
+        } else {
+            vw[j] = (uint32_t)r * (uint32_t)a.ldw * 2u + (uint32_t)c * 16u;
+        }
+    }
+    const uint32_t xhalf = 128u * (uint32_t)a.ldx * 2u;                      // second half-tile: 128 rows further
+    const uint32_t whalf = WT ? 256u : 128u * (uint32_t)a.ldw * 2u;         // WT: 128 columns further
+    const uint32_t dst0 = (uint32_t)wave * 1024u;                            // + 8192 j + HALF * slot + BUF * buffer
+
+    // ---- fragment read bases (bytes inside a buffer)
+    //   K-contiguous: row r = 16 T + (lane & 15) of the half-tile, chunk 4 ks + (lane >> 4):
+    //     (r >> 3) * 1024 + (r & 7) * 128 + ((chunk ^ ((r >> 1) & 7)) * 16)  ->  T * 2048 + lanepart(ks)
+    const uint32_t lp0 = (uint32_t)(((lane >> 3) & 1) * 1024 + (lane & 7) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) * 16));
+    const uint32_t xb0 = (uint32_t)wr * HALF + lp0, xb1 = xb0 ^ 64u;
+    const uint32_t wb0 = 2u * HALF + (uint32_t)(wc >> 1) * HALF + (uint32_t)(wc & 1) * 4u * 2048u + lp0, wb1 = wb0 ^ 64u;
+    //   K-strided (WT): half-tile (wc >> 1) = columns 128 (wc >> 1) .. + 127 of the tile; the wave's 64 columns = column half
+    //   ch = wc & 1 of every k-block.  Fragment (column tile T of 16, k-step ks): lane 4 q + p of 16-lane group g reads k-row
+    //   8 g + q (lo) / 8 g + 4 + q (hi) of k-block kb = 4 ks + g, columns 16 T + 4 p .. + 3:
+    //     piece (2 kb + ch) * 1024 + krow * 128 + ((2 (T & 3)... the wave's 64 columns are ONE column half: 32-byte block cb = T (0..3)
+    //     byte = cb' * 32 + p * 8, cb' = cb ^ f(kb, krow)
+    uint32_t wt_lo[2][4], wt_hi[2][4];
+    if (WT) {
+        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                const int kb = 4 * ks + g;
+                const int flo = ((kb & 1) << 1) | ((q >> 1) & 1), fhi = ((kb & 1) << 1) | (((4 + q) >> 1) & 1);
+                const uint32_t pbase = 2u * HALF + (uint32_t)(wc >> 1) * HALF + (uint32_t)(2 * kb + (wc & 1)) * 1024u;
+                wt_lo[ks][T] = pbase + (uint32_t)(q * 128 + ((T ^ flo) * 32) + p * 8);
+                wt_hi[ks][T] = pbase + (uint32_t)((4 + q) * 128 + ((T ^ fhi) * 32) + p * 8);
+            }
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+    Cursor<MODE> cons, prod, prodx;          // consumer; producer of X1 / W0 / W1 (one K-tile ahead) and of X0 (two ahead)
+    cons.start(a);
+    prod = cons;
+    prodx = cons;
+
+    // slot: 0 X0, 1 X1, 2 W0, 3 W1
+    auto stage = [&](const Cursor<MODE> &c, int slot, int buf) {
+        const uint32_t d = dst0 + (uint32_t)slot * HALF + (uint32_t)buf * BUF;
+        if (slot < 2) {
+            const uint32_t so = (uint32_t)c.kt * 128u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rx, (__attribute__((address_space(3))) void *)(lds + d + 8192u * j), 16,
+                                                         vx[j] + (slot == 1 ? xhalf : 0u), so, 0, 0);
+        } else {
+            const uint32_t so = WT ? 0u : (uint32_t)c.kt * 128u;                  // WT: the descriptor itself walks down the rows
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rw, (__attribute__((address_space(3))) void *)(lds + d + 8192u * j), 16,
+                                                         vw[j] + (slot == 3 ? whalf : 0u), so, 0, 0);
+        }
+    };
+
+    // ---- prologue: K-tile 0 complete, X0 of K-tile 1 in flight
+    stage(prod, 0, 0);
+    stage(prod, 1, 0);
+    stage(prod, 2, 0);
+    stage(prod, 3, 0);
+    prod.advance(a);                          // -> K-tile 1
+    prodx.advance(a);
+    if (prodx.valid) {
+        stage(prodx, 0, 1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    prodx.advance(a);                         // -> K-tile 2
+    __builtin_amdgcn_s_barrier();
+    if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+    // quadrant (MH, NH) of item `it` -> memory, and its accumulators back to zero
+    auto flush = [&](const Item &it, int MH, int NH) {
+        if (MODE == MODE_DW) {
+            // stream-K segment: f32 [256 j][256 n] of this tile, row-major
+            float *o = reinterpret_cast<float *>(a.out) + (size_t)it.aux * (BM * BN) + (size_t)(wr * 128 + (lane & 15)) * BN + wc * 64 + 4 * (lane >> 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    *reinterpret_cast<f32x4 *>(o + (size_t)(16 * (4 * MH + mt)) * BN + 16 * (2 * NH + nt)) = acc[4 * MH + mt][2 * NH + nt];
+        } else {
+            const int mrow = it.m0 + wr * 128 + (lane & 15), ncol = it.n0 + wc * 64 + 4 * (lane >> 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = mrow + 16 * (4 * MH + mt);
+                if (m < a.M) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const f32x4 v = acc[4 * MH + mt][2 * NH + nt];
+                        if (MODE == MODE_FWD) {
+                            float *o = reinterpret_cast<float *>(a.out) + (size_t)it.aux * a.M * a.ldo;
+                            *reinterpret_cast<f32x4 *>(o + (size_t)m * a.ldo + ncol + 16 * (2 * NH + nt)) = v;
+                        } else {
+                            bf16x4 h;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[e] = (bf16)v[e];
+                            *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(a.out) + (size_t)m * a.ldo + ncol + 16 * (2 * NH + nt)) = h;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[4 * MH + mt][2 * NH + nt] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    };
+    Item pend = cons.it;
+    bool have_pend = false;
+
+    bf16x8 xf[2][4], wf[2][2];
+    int buf = 0;
+    while (cons.valid) {
+        const lds_byte *const lb = lds + (uint32_t)buf * BUF;
+        auto read_x = [&](int MH) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                xf[0][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + xb0 + (uint32_t)(4 * MH + mt) * 2048u);
+                xf[1][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + xb1 + (uint32_t)(4 * MH + mt) * 2048u);
+            }
+        };
+        auto read_w = [&](int NH) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (WT) {
+                    wf[0][nt] = tr_frag(lb + wt_lo[0][2 * NH + nt], lb + wt_hi[0][2 * NH + nt]);
+                    wf[1][nt] = tr_frag(lb + wt_lo[1][2 * NH + nt], lb + wt_hi[1][2 * NH + nt]);
+                } else {
+                    wf[0][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + wb0 + (uint32_t)(2 * NH + nt) * 2048u);
+                    wf[1][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + wb1 + (uint32_t)(2 * NH + nt) * 2048u);
+                }
+            }
+        };
+        auto mma = [&](int MH, int NH) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[4 * MH + mt][2 * NH + nt] = mfma(wf[ks][nt], xf[ks][mt], acc[4 * MH + mt][2 * NH + nt]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto seg = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // phase 0: quadrant (rows 0-63, columns 0-31); request X1 of the next K-tile
+        read_w(0);
+        read_x(0);
+        if (prod.valid) stage(prod, 1, buf ^ 1);
+        if (have_pend) flush(pend, 0, 0);
+        seg();
+        mma(0, 0);
+        seg();
+        // phase 1: (rows 0-63, columns 32-63); request W0
+        read_w(1);
+        if (prod.valid) stage(prod, 2, buf ^ 1);
+        if (have_pend) flush(pend, 0, 1);
+        seg();
+        mma(0, 1);
+        seg();
+        // phase 2: (rows 64-127, columns 32-63); request W1
+        read_x(1);
+        if (prod.valid) stage(prod, 3, buf ^ 1);
+        if (have_pend) flush(pend, 1, 1);
+        seg();
+        mma(1, 1);
+        seg();
+        // phase 3: (rows 64-127, columns 0-31); request X0 of the K-tile after next into THIS buffer (its X0 was last read in phase 2),
+        // then wait for everything but those two requests: the next K-tile is complete.  (The pending quadrant's stores go out
+        // AFTER the wait: vmcnt retires in order, younger stores do not hold it up.)
+        read_w(0);
+        if (prodx.valid) {
+            stage(prodx, 0, buf);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (have_pend) {
+            flush(pend, 1, 0);
+            have_pend = false;
+        }
+        seg();
+        mma(1, 0);
+
+        prod.advance(a);
+        prodx.advance(a);
+        // consumer: at the end of an item its tile is complete; the four quadrants leave in the load segments of the NEXT K-tile
+        // (one per phase, each right before the phase that starts the next item's sum in those registers), where they cost
+        // nothing: the partner wave of the SIMD is in its MFMA segment
+        if (cons.kt + 1 == cons.it.kt1) {
+            pend = cons.it;
+            have_pend = true;
+        }
+        cons.advance(a);
+        seg();
+        buf ^= 1;
+    }
+    if (have_pend) {
+        flush(pend, 0, 0);
+        flush(pend, 0, 1);
+        flush(pend, 1, 1);
+        flush(pend, 1, 0);
+    }
+    if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+#else
+    (void)a;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient, second half: sum the stream-K segment slabs of every tile and write the f32 gradient in the MODULE's layout
+// grad_w[j][c P + p] (nn.Flatten's order of the reference's features, policies.py:102) from the kernels' feature order p 128 + c,
+// plus the four extra-feature columns (dwe, from inv_heads_bwd).  One workgroup = (row j, chunk of 32 pixels): 16 K-contiguous
+// 1-KB rows per covering segment in, 128 runs of 32 consecutive floats out, transposed through LDS.
+struct DwReduceArgs {
+    const float *segs;                   // [streams][maxseg][tiles_m][256][256]
+    const float *dwe;                    // [rows][4]
+    float *gw[2];                        // per head: [256][128 P + 4]
+    int P, tiles_m, ktiles, per, maxseg, nstreams;
+};
+
+__global__ __launch_bounds__(256) void k_fc1_dw_reduce(DwReduceArgs r)
+{
+    __shared__ float tl[128 * 33];
+    const int j = blockIdx.y, p0 = blockIdx.x * 32, tid = threadIdx.x;
+    const int np = min(32, r.P - p0);
+    const int mt = j >> 8, jr = j & 255;
+    // features [128 p0, 128 (p0 + np)): 4 per thread and pass; a column tile of 256 = 2 pixels
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + tid, dp = idx >> 5;                         // pixel p0 + dp, channels 4 (idx & 31) .. + 3
+        if (dp < np) {
+            const int f = (p0 + dp) * 128 + 4 * (idx & 31), n = f >> 8;
+            const long long b0 = (long long)n * r.ktiles, b1 = b0 + r.ktiles;
+            const int q0 = (int)(b0 / r.per), q1 = (int)((b1 - 1) / r.per);
+            float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int q = q0; q <= q1 && q < r.nstreams; ++q) {
+                const int seq = n - (int)(((long long)q * r.per) / r.ktiles);
+                const float4 v = *reinterpret_cast<const float4 *>(r.segs + (((size_t)(q * r.maxseg + seq) * r.tiles_m + mt) * 256 + jr) * 256 + (f & 255));
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const int c = 4 * (idx & 31);
+            tl[(c + 0) * 33 + dp] = s.x; tl[(c + 1) * 33 + dp] = s.y; tl[(c + 2) * 33 + dp] = s.z; tl[(c + 3) * 33 + dp] = s.w;
+        }
+    }
+    __syncthreads();
+    const int nf = 128 * r.P, ld = nf + 4;
+    float *dst = r.gw[j >> 8] + (size_t)(j & 255) * ld;
+    for (int i = tid; i < 128 * 32; i += 256) {
+        const int c = i >> 5, dp = i & 31;
+        if (dp < np) dst[c * r.P + p0 + dp] = tl[c * 33 + dp];
+    }
+    if (blockIdx.x == 0 && tid < 4) dst[nf + tid] = r.dwe[j * 4 + tid];
+}
+
+} // namespace fc1
+
+static int fc1_status(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return INV_OK;
+}
+
+template <int MODE>
+static int fc1_launch(const fc1::Args &a, int grid, hipStream_t st, const char *what)
+{
+    static bool attr_done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!attr_done[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
+        if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "%s: hipFuncSetAttribute(%d B of LDS): %s", what, fc1::LDS_BYTES, hipGetErrorString(e));
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((fc1::k_fc1_gemm<MODE, true>), dim3(grid), dim3(fc1::THREADS), fc1::LDS_BYTES, st, a);
+    return fc1_status(what);
+}
+
+static int fc1_fwd_split(int B, int nout, int K)
+{
+    const int tiles = ((B + fc1::BM - 1) / fc1::BM) * (nout / fc1::BN), ktiles = K / fc1::BK;
+    int s = inv_cu_count() / (tiles > 0 ? tiles : 1);
+    if (s > 8) s = 8;
+    if (s > ktiles / 8) s = ktiles / 8;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int32_t inv_fc1_fwd_slabs(int32_t B, int32_t nout, int32_t K)
+{
+    if (B <= 0 || nout <= 0 || nout % fc1::BN || K <= 0 || K % fc1::BK) return 0;
+    return fc1_fwd_split(B, nout, K);
+}
+
+extern "C" int inv_fc1_fwd(const void *feat_bf16, const void *wf_bf16, int32_t B, int32_t nout, int32_t K, float *pre_slabs, void *stream)
+{
+    if (!feat_bf16 || !wf_bf16 || !pre_slabs || B < 0 || nout <= 0 || nout % fc1::BN || K <= 0 || K % fc1::BK)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_fc1_fwd: NULL pointer, B < 0, nout not a multiple of 256 or K not a multiple of 64");
+    if (B == 0) return INV_OK;
+    if ((long long)fc1::BM * K * 2 > 0x7fffffffLL) return inv_fail(INV_ERR_BAD_ARG, "inv_fc1_fwd: K too large for 32-bit tile offsets");
+    fc1::Args a = {};
+    a.X = reinterpret_cast<const fc1::bf16 *>(feat_bf16);
+    a.W = reinterpret_cast<const fc1::bf16 *>(wf_bf16);
+    a.out = pre_slabs;
+    a.M = B; a.N = nout; a.K = K; a.ldx = K; a.ldw = K; a.ldo = nout;
+    a.tiles_m = (B + fc1::BM - 1) / fc1::BM; a.tiles_n = nout / fc1::BN; a.ktiles = K / fc1::BK;
+    a.split = fc1_fwd_split(B, nout, K);
+    a.total = a.tiles_m * a.tiles_n * a.split;
+    return fc1_launch<fc1::MODE_FWD>(a, a.total, (hipStream_t)stream, "inv_fc1_fwd");
+}
+
+extern "C" int inv_fc1_dfeat(const void *dpre_bf16, const void *wft_bf16, int32_t B, int32_t nhid, int32_t nfeat, void *dfeat_bf16, void *stream)
+{
+    if (!dpre_bf16 || !wft_bf16 || !dfeat_bf16 || B < 0 || nhid <= 0 || nhid % fc1::BK || nfeat <= 0 || nfeat % fc1::BN)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_fc1_dfeat: NULL pointer, B < 0, nhid not a multiple of 64 or nfeat not a multiple of 256");
+    if (B == 0) return INV_OK;
+    fc1::Args a = {};
+    a.X = reinterpret_cast<const fc1::bf16 *>(dpre_bf16);
+    a.W = reinterpret_cast<const fc1::bf16 *>(wft_bf16);
+    a.out = dfeat_bf16;
+    a.M = B; a.N = nfeat; a.K = nhid; a.ldx = nhid; a.ldw = nhid; a.ldo = nfeat;
+    a.tiles_m = (B + fc1::BM - 1) / fc1::BM; a.tiles_n = nfeat / fc1::BN; a.ktiles = nhid / fc1::BK;
+    a.split = 1;
+    a.total = a.tiles_m * a.tiles_n;
+    const int cus = inv_cu_count();
+    return fc1_launch<fc1::MODE_DFEAT>(a, a.total < cus ? a.total : cus, (hipStream_t)stream, "inv_fc1_dfeat");
+}
+
+struct Fc1DwPlan { int tiles_m, tiles_n, ktiles, per, streams, maxseg; };
+static Fc1DwPlan fc1_dw_plan(int Bpad, int nhid, int nfeat)
+{
+    Fc1DwPlan p;
+    p.tiles_m = nhid / fc1::BM; p.tiles_n = nfeat / fc1::BN; p.ktiles = Bpad / fc1::BK;
+    const long long units = (long long)p.tiles_n * p.ktiles;                      // (column tile, K-tile) pairs, each worked on by tiles_m workgroups
+    int want = inv_cu_count() / p.tiles_m;
+    if (want < 1) want = 1;
+    p.per = (int)((units + want - 1) / want);
+    p.streams = (int)((units + p.per - 1) / p.per);
+    p.maxseg = p.per / p.ktiles + 2;
+    return p;
+}
+
+extern "C" int64_t inv_fc1_dw_workspace_bytes(int32_t B, int32_t nhid, int32_t nfeat)
+{
+    if (B <= 0 || nhid <= 0 || nhid % fc1::BM || nfeat <= 0 || nfeat % fc1::BN) return 0;
+    const Fc1DwPlan p = fc1_dw_plan((B + 63) / 64 * 64, nhid, nfeat);
+    return (int64_t)p.streams * p.maxseg * p.tiles_m * fc1::BM * fc1::BN * (int64_t)sizeof(float);
+}
+
+extern "C" int inv_fc1_dw(const void *dpre_t_bf16, const void *feat_bf16, const float *dwe, int32_t B, int32_t nhid, int32_t pixels,
+                          float *grad_w_actor, float *grad_w_critic, void *workspace, void *stream)
+{
+    const int nfeat = 128 * pixels, Bpad = (B + 63) / 64 * 64;
+    if (!dpre_t_bf16 || !feat_bf16 || !dwe || !grad_w_actor || (nhid > 256 && !grad_w_critic) || !workspace || B < 0 || (nhid != 256 && nhid != 512) ||
+        pixels <= 0 || nfeat % fc1::BN)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_fc1_dw: NULL pointer, B < 0, nhid not 256 | 512 or 128 * pixels not a multiple of 256");
+    if (B == 0) return INV_OK;
+    if ((long long)fc1::BM * Bpad * 2 > 0x7fffffffLL || 64LL * nfeat * 2 > 0x7fffffffLL) return inv_fail(INV_ERR_BAD_ARG, "inv_fc1_dw: B or pixels too large for 32-bit tile offsets");
+    const Fc1DwPlan p = fc1_dw_plan(Bpad, nhid, nfeat);
+    fc1::Args a = {};
+    a.X = reinterpret_cast<const fc1::bf16 *>(dpre_t_bf16);      // [nhid][Bpad], columns past B zero
+    a.W = reinterpret_cast<const fc1::bf16 *>(feat_bf16);        // [B][nfeat]
+    a.out = workspace;
+    a.M = nhid; a.N = nfeat; a.K = B; a.ldx = Bpad; a.ldw = nfeat; a.ldo = fc1::BN;
+    a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.ktiles = p.ktiles; a.split = p.maxseg; a.total = p.per;
+    const int rc = fc1_launch<fc1::MODE_DW>(a, p.streams * p.tiles_m, (hipStream_t)stream, "inv_fc1_dw");
+    if (rc != INV_OK) return rc;
+    fc1::DwReduceArgs r = { reinterpret_cast<const float *>(workspace), dwe, { grad_w_actor, grad_w_critic }, pixels, p.tiles_m, p.ktiles, p.per, p.maxseg, p.streams };
+    hipLaunchKernelGGL(fc1::k_fc1_dw_reduce, dim3((pixels + 31) / 32, nhid), dim3(256), 0, (hipStream_t)stream, r);
+    return fc1_status("inv_fc1_dw (reduce)");
+}

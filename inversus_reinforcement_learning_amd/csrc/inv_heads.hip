@@ -1,8 +1,9 @@
 // inv_heads.hip -- the heads of InversusCNNPolicy after their first Linear, fused:
 //   reference: inversus_rl/policies.py:60-75 (fc_actor / fc_critic: Linear(19204, 256) ReLU Linear(256, 128) ReLU Linear(128, 13 | 1))
 //              and :102-106 (features ++ extra -> logits, value), run under autograd in ppo_agent.py:206-230.
-// The big GEMM  pre = features @ W1[:, :19200]^T  ([B x 19200] x [19200 x 512] bf16) stays with the GEMM library.  Everything after
-// it is tiny per sample (0.13 MFLOP) but was ~25 torch launches forward and ~60 backward over [B x 512] / [B x 128] tensors:
+// The big GEMM  pre = features @ W1[:, :19200]^T  ([B x 19200] x [19200 x 512] bf16) and its two backward products are
+// csrc/inv_fc1.hip.  Everything after it is tiny per sample (0.13 MFLOP) but was ~25 torch launches forward and ~60 backward over
+// [B x 512] / [B x 128] tensors:
 //   inv_heads_fwd   h = relu(pre + extra W1e^T + b1);  a2 = relu(W2 h + b2);  logits / value = W3 a2 + b3          (one kernel)
 //   inv_heads_bwd   d logits, d value -> d a2 -> d pre (bf16, the operand of the two big backward GEMMs) and the gradients of
 //                   b1, W1e, b2, W3, b3                                                                             (one kernel)
@@ -38,7 +39,7 @@ __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __bu
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 template <bool SAVE>
-__global__ __launch_bounds__(THREADS, 2) void k_heads_fwd(inv_heads_params prm, const bf16 *__restrict__ pre, const float *__restrict__ extra,
+__global__ __launch_bounds__(THREADS, 2) void k_heads_fwd(inv_heads_params prm, const float *__restrict__ pre, int nslabs, const float *__restrict__ extra,
                                                           float *__restrict__ logits, float *__restrict__ value,
                                                           bf16 *__restrict__ h_save, bf16 *__restrict__ a2_save, int nheads, int B)
 {
@@ -81,16 +82,23 @@ __global__ __launch_bounds__(THREADS, 2) void k_heads_fwd(inv_heads_params prm, 
 
     for (int t = blk; t < ntiles; t += nblk) {
         const int s0 = t * S;
-        // layer 1 epilogue: pre (bf16, the GEMM's output) + b1 + extra W1e^T, ReLU -> h (bf16) in the tile
+        // layer 1 epilogue: pre (the f32 split-K slabs of inv_fc1_fwd, added in slab order) + b1 + extra W1e^T, ReLU -> h (bf16) in the tile
 #pragma unroll
         for (int i = 0; i < S / 8; ++i) {
             const int r = row0 + 8 * i, s = min(s0 + r, B - 1);           // rows past B re-read the last sample; never stored
-            const bf16x8 pv = *reinterpret_cast<const bf16x8 *>(pre + (size_t)s * RL + head * HID + part * 8);
+            const float *pp = pre + (size_t)s * RL + head * HID + part * 8;
+            float4 p0 = reinterpret_cast<const float4 *>(pp)[0], p1 = reinterpret_cast<const float4 *>(pp)[1];
+            for (int k = 1; k < nslabs; ++k) {
+                const float4 q0 = reinterpret_cast<const float4 *>(pp + (size_t)k * B * RL)[0], q1 = reinterpret_cast<const float4 *>(pp + (size_t)k * B * RL)[1];
+                p0.x += q0.x; p0.y += q0.y; p0.z += q0.z; p0.w += q0.w;
+                p1.x += q1.x; p1.y += q1.y; p1.z += q1.z; p1.w += q1.w;
+            }
+            const float pv[8] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w };
             const float4 ex = reinterpret_cast<const float4 *>(extra)[s];
             bf16x8 hv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float v = (float)pv[e] + b1v[e];
+                float v = pv[e] + b1v[e];
                 v = fmaf(ex.x, wev[e].x, v); v = fmaf(ex.y, wev[e].y, v); v = fmaf(ex.z, wev[e].z, v); v = fmaf(ex.w, wev[e].w, v);
                 hv[e] = (bf16)fmaxf(v, 0.0f);
             }
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_heads_fwd(inv_heads_params prm, 
 //   d W3[a][j] = sum_s d out[s][a] a2[s][j]          d b3[a] = sum_s d out[s][a]
 __global__ __launch_bounds__(THREADS, 2) void k_heads_bwd(inv_heads_params prm, const float *__restrict__ dlogits, const float *__restrict__ dvalue,
                                                           const bf16 *__restrict__ h, const bf16 *__restrict__ a2, const float *__restrict__ extra,
-                                                          bf16 *__restrict__ dpre, bf16 *__restrict__ dpre_t, bf16 *__restrict__ da2,
+                                                          bf16 *__restrict__ dpre, bf16 *__restrict__ dpre_t, int ldt, bf16 *__restrict__ da2,
                                                           inv_heads_grads gr, int B)
 {
     __shared__ __attribute__((aligned(16))) bf16 tileH[S * HS];     // h, then d pre in place
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_heads_bwd(inv_heads_params prm, 
         }
         {
             // column `tid` of the tile: its sums, and (dpre_t) the same 32 values as one 64-byte piece of row k of d pre^T -- the
-            // K-contiguous operand that lets the library run  dW1 = d pre^T @ features  as a plain NN product (0.39 vs 0.55 ms)
+            // K-contiguous operand of the weight-gradient product  dW1 = d pre^T @ features  (inv_fc1_dw)
             float sb = 0.0f, se[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll 8
             for (int r = 0; r < S; ++r) {
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_heads_bwd(inv_heads_params prm, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) g_we[e] += se[e];
             if (dpre_t) {
-                bf16 *dst = dpre_t + (size_t)(head * HID + tid) * B + s0;
+                bf16 *dst = dpre_t + (size_t)(head * HID + tid) * ldt + s0;
                 if (s0 + S <= B) {
                     for (int i = 0; i < S / 8; ++i) {                            // not unrolled: 4 registers live, not 16
                         bf16x8 col;
@@ -353,6 +361,81 @@ __global__ __launch_bounds__(THREADS, 2) void k_heads_bwd(inv_heads_params prm, 
             if (a3lo + a < nact) atomicAdd(gr.dw3[head] + (size_t)(a3lo + a) * MID + j3, g_w3[a]);
     }
     if (tid < nact) atomicAdd(gr.db3[head] + tid, g_b3);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the heads' second Linear:  dW2[h][j][k] = sum_s d a2[s][128 h + j] * hs[s][256 h + k]   (j < 128, k < 256).
+// The contraction runs over SAMPLES, the row index of both saved tensors, so both MFMA operands come from the transposing LDS
+// read (rows = samples).  Block = (head, chunk of 256 samples), 4 waves; wave w owns output rows 32 w .. 32 w + 31 x all 256 columns
+// (32 accumulator tiles) over the chunk's eight 32-sample steps and ADDS them with f32 atomics (64 contiguous bytes per 16-lane group).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_frag(const bf16 *row_lo, const bf16 *row_hi)
+{
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(row_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(row_hi));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int DW2_CHUNK = 256;
+
+__global__ __launch_bounds__(THREADS) void k_heads_dw2(const bf16 *__restrict__ da2, const bf16 *__restrict__ hs, float *__restrict__ dw2a,
+                                                       float *__restrict__ dw2c, int B)
+{
+    __shared__ __attribute__((aligned(16))) bf16 tileD[S * AS];      // d a2 [32 samples][128]
+    __shared__ __attribute__((aligned(16))) bf16 tileH[S * HS];      // h    [32 samples][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
+    const int head = (int)blockIdx.x & 1, chunk = (int)blockIdx.x >> 1;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p4 = (lane & 3) * 4;
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 16; ++ni) acc[mi][ni] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const int send = min(B, (chunk + 1) * DW2_CHUNK);
+    for (int s0 = chunk * DW2_CHUNK; s0 < send; s0 += S) {
+        __syncthreads();                                             // the previous step's reads are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * THREADS, r = c >> 4, pc = c & 15;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
+            if (s0 + r < B) v = *reinterpret_cast<const bf16x8 *>(da2 + (size_t)(s0 + r) * (2 * MID) + head * MID + pc * 8);
+            *reinterpret_cast<bf16x8 *>(tileD + r * AS + pc * 8) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * THREADS, r = c >> 5, pc = c & 31;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
+            if (s0 + r < B) v = *reinterpret_cast<const bf16x8 *>(hs + (size_t)(s0 + r) * (2 * HID) + head * HID + pc * 8);
+            *reinterpret_cast<bf16x8 *>(tileH + r * HS + pc * 8) = v;
+        }
+        __syncthreads();
+        bf16x8 af[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+            af[mi] = tr_frag(tileD + (8 * g + q) * AS + (2 * wave + mi) * 16 + p4, tileD + (8 * g + 4 + q) * AS + (2 * wave + mi) * 16 + p4);
+#pragma unroll
+        for (int ni = 0; ni < 16; ++ni) {
+            const bf16x8 bfr = tr_frag(tileH + (8 * g + q) * HS + ni * 16 + p4, tileH + (8 * g + 4 + q) * HS + ni * 16 + p4);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma(af[mi], bfr, acc[mi][ni]);
+        }
+    }
+    float *dst = head == 0 ? dw2a : dw2c;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 16; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dst + (size_t)((2 * wave + mi) * 16 + 4 * g + e) * HID + ni * 16 + (lane & 15), acc[mi][ni][e]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -408,18 +491,6 @@ __global__ __launch_bounds__(256) void k_transpose_bf16(const bf16 *__restrict__
     }
 }
 
-// ... and its gradient back: dwf bf16 [rows][128 P] (p * 128 + c), dwe f32 [rows][4] -> f32 [rows][128 P + 4] in the module's order.
-// Reads are made contiguous (the 2-byte side), writes scatter with stride P.
-__global__ __launch_bounds__(256) void k_unpack_fc1_grad(const bf16 *__restrict__ dwf, const float *__restrict__ dwe, int P, float *__restrict__ gw)
-{
-    const int r = blockIdx.y, nf = 128 * P, ld = nf + 4;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf; i += gridDim.x * 256) {
-        const int c = i / P, p = i - c * P;                  // contiguous f32 writes; the bf16 reads stride by 256 B (L2 absorbs them)
-        gw[(size_t)r * ld + i] = (float)dwf[(size_t)r * nf + p * 128 + c];
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 4) gw[(size_t)r * ld + nf + threadIdx.x] = dwe[r * 4 + threadIdx.x];
-}
-
 } // namespace hd
 
 static int heads_status(const char *what)
@@ -468,14 +539,6 @@ extern "C" int inv_transpose_bf16(const void *in_bf16, int32_t rows, int32_t col
     return heads_status("inv_transpose_bf16");
 }
 
-extern "C" int inv_heads_unpack_fc1_grad(const void *dwf_bf16, const float *dwe, int32_t rows, int32_t pixels, float *grad_w, void *stream)
-{
-    if (!dwf_bf16 || !dwe || !grad_w || rows <= 0 || pixels <= 0) return inv_fail(INV_ERR_BAD_ARG, "inv_heads_unpack_fc1_grad: NULL pointer or rows / pixels <= 0");
-    hipLaunchKernelGGL(hd::k_unpack_fc1_grad, dim3(min(64, (128 * pixels + 255) / 256), rows), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const hd::bf16 *>(dwf_bf16), dwe, pixels, grad_w);
-    return heads_status("inv_heads_unpack_fc1_grad");
-}
-
 static int heads_grid(int B, int nheads)
 {
     const int tiles = (B + hd::S - 1) / hd::S;
@@ -483,33 +546,43 @@ static int heads_grid(int B, int nheads)
     return per_head * nheads;
 }
 
-extern "C" int inv_heads_fwd(const inv_heads_params *params, const void *pre_bf16, const float *extra, float *logits, float *value,
+extern "C" int inv_heads_fwd(const inv_heads_params *params, const float *pre_slabs, int32_t nslabs, const float *extra, float *logits, float *value,
                              void *h_save, void *a2_save, int32_t nheads, int32_t B, void *stream)
 {
-    if ((nheads != 1 && nheads != 2) || B < 0 || !heads_params_ok(params, nheads, false) || !pre_bf16 || !extra || !logits || (nheads == 2 && !value) ||
+    if ((nheads != 1 && nheads != 2) || B < 0 || nslabs < 1 || !heads_params_ok(params, nheads, false) || !pre_slabs || !extra || !logits || (nheads == 2 && !value) ||
         ((h_save != nullptr) != (a2_save != nullptr)))
-        return inv_fail(INV_ERR_BAD_ARG, "inv_heads_fwd: nheads not 1 | 2, B < 0, a NULL parameter / input / output, or only one of h_save / a2_save");
+        return inv_fail(INV_ERR_BAD_ARG, "inv_heads_fwd: nheads not 1 | 2, B < 0, nslabs < 1, a NULL parameter / input / output, or only one of h_save / a2_save");
     if (B == 0) return INV_OK;
     const dim3 grid(heads_grid(B, nheads));
     if (h_save)
-        hipLaunchKernelGGL(hd::k_heads_fwd<true>, grid, dim3(hd::THREADS), 0, (hipStream_t)stream, *params, reinterpret_cast<const hd::bf16 *>(pre_bf16), extra,
+        hipLaunchKernelGGL(hd::k_heads_fwd<true>, grid, dim3(hd::THREADS), 0, (hipStream_t)stream, *params, pre_slabs, (int)nslabs, extra,
                            logits, value, reinterpret_cast<hd::bf16 *>(h_save), reinterpret_cast<hd::bf16 *>(a2_save), (int)nheads, (int)B);
     else
-        hipLaunchKernelGGL(hd::k_heads_fwd<false>, grid, dim3(hd::THREADS), 0, (hipStream_t)stream, *params, reinterpret_cast<const hd::bf16 *>(pre_bf16), extra,
+        hipLaunchKernelGGL(hd::k_heads_fwd<false>, grid, dim3(hd::THREADS), 0, (hipStream_t)stream, *params, pre_slabs, (int)nslabs, extra,
                            logits, value, nullptr, nullptr, (int)nheads, (int)B);
     return heads_status("inv_heads_fwd");
 }
 
 extern "C" int inv_heads_bwd(const inv_heads_params *params, const float *dlogits, const float *dvalue, const void *h, const void *a2, const float *extra,
-                             void *dpre_bf16, void *dpre_t_bf16, void *da2_bf16, const inv_heads_grads *grads, int32_t B, void *stream)
+                             void *dpre_bf16, void *dpre_t_bf16, int32_t dpre_t_ld, void *da2_bf16, const inv_heads_grads *grads, int32_t B, void *stream)
 {
-    if (dpre_t_bf16 && B % 8 != 0) return inv_fail(INV_ERR_BAD_ARG, "inv_heads_bwd: dpre_t needs B %% 8 == 0 (16-byte rows), got B = %d", (int)B);
+    if (dpre_t_bf16 && (dpre_t_ld < B || dpre_t_ld % 8 != 0))
+        return inv_fail(INV_ERR_BAD_ARG, "inv_heads_bwd: dpre_t needs a leading dimension >= B that is a multiple of 8 (16-byte rows), got %d for B = %d", (int)dpre_t_ld, (int)B);
     if (B < 0 || !heads_params_ok(params, 2, true) || !dlogits || !dvalue || !h || !a2 || !extra || !dpre_bf16 || !da2_bf16 || !grads || !grads->db1 || !grads->dwe ||
         !grads->db2[0] || !grads->db2[1] || !grads->dw3[0] || !grads->dw3[1] || !grads->db3[0] || !grads->db3[1])
         return inv_fail(INV_ERR_BAD_ARG, "inv_heads_bwd: B < 0 or a NULL parameter / input / output / gradient buffer");
     if (B == 0) return INV_OK;
     hipLaunchKernelGGL(hd::k_heads_bwd, dim3(heads_grid(B, 2)), dim3(hd::THREADS), 0, (hipStream_t)stream, *params, dlogits, dvalue,
                        reinterpret_cast<const hd::bf16 *>(h), reinterpret_cast<const hd::bf16 *>(a2), extra, reinterpret_cast<hd::bf16 *>(dpre_bf16),
-                       reinterpret_cast<hd::bf16 *>(dpre_t_bf16), reinterpret_cast<hd::bf16 *>(da2_bf16), *grads, (int)B);
+                       reinterpret_cast<hd::bf16 *>(dpre_t_bf16), (int)dpre_t_ld, reinterpret_cast<hd::bf16 *>(da2_bf16), *grads, (int)B);
     return heads_status("inv_heads_bwd");
+}
+
+extern "C" int inv_heads_dw2(const void *da2_bf16, const void *h_bf16, int32_t B, float *dw2_actor, float *dw2_critic, void *stream)
+{
+    if (!da2_bf16 || !h_bf16 || !dw2_actor || !dw2_critic || B < 0) return inv_fail(INV_ERR_BAD_ARG, "inv_heads_dw2: NULL pointer or B < 0");
+    if (B == 0) return INV_OK;
+    hipLaunchKernelGGL(hd::k_heads_dw2, dim3(2 * ((B + hd::DW2_CHUNK - 1) / hd::DW2_CHUNK)), dim3(hd::THREADS), 0, (hipStream_t)stream,
+                       reinterpret_cast<const hd::bf16 *>(da2_bf16), reinterpret_cast<const hd::bf16 *>(h_bf16), dw2_actor, dw2_critic, (int)B);
+    return heads_status("inv_heads_dw2");
 }

@@ -1,7 +1,10 @@
-"""Host side of csrc/inv_heads.hip: the two heads of InversusCNNPolicy (inversus_rl/policies.py:60-75, :102-106) after the trunk.
+"""Host side of csrc/inv_fc1.hip + csrc/inv_heads.hip: the two heads of InversusCNNPolicy (inversus_rl/policies.py:60-75, :102-106)
+after the trunk.
 
-    pre    = features @ W1[:, :128 P]^T                      the GEMM library ([B x 128 P] x [128 P x 512] bf16)
+    pre    = inv_fc1_fwd(features, W1[:, :128 P])            [B x 128 P] x [128 P x 512] bf16 MFMA kernel, f32 split-K slabs
     logits, value = inv_heads_fwd(pre, extra)                one kernel (first-layer epilogue, Linear 256 -> 128, Linear 128 -> 13 | 1)
+
+The backward's two big products (d features, d W1) are inv_fc1_dfeat / inv_fc1_dw, d W2 is inv_heads_dw2: no GEMM-library call.
 
 `HeadsOperands` packs a policy's head parameters for the kernels (rollouts: once per refresh); `heads_train` is the differentiable
 form the fused PPO update uses (packs per call -- the parameters change every minibatch -- and returns gradients for all 12 head
@@ -94,14 +97,22 @@ class HeadsOperands:
         """feat bf16 [B, 128 P], extra f32 [B, 4] -> logits f32 [B, 13], value f32 [B, 1] | None (+ (pre... h, a2) when save)."""
         lib = L.load()
         B, n = feat.shape[0], self.nheads
-        pre = feat @ self.wf.t()                                                       # bf16 [B, 256 n], f32 accumulation
+        if feat.dtype != torch.bfloat16 or feat.dim() != 2 or feat.shape[1] != self.wf.shape[1] or not feat.is_contiguous():
+            raise ValueError(f"features must be contiguous bf16 [B, {self.wf.shape[1]}], got {tuple(feat.shape)} {feat.dtype}")
+        K = feat.shape[1]
+        with torch.cuda.device(feat.device):
+            slabs = int(lib.inv_fc1_fwd_slabs(B, HID * n, K)) if B > 0 else 1
+            if slabs < 1:
+                raise ValueError(f"inv_fc1_fwd does not support B = {B}, nout = {HID * n}, K = {K}")
+            pre = torch.empty((slabs, B, HID * n), dtype=torch.float32, device=feat.device)   # f32 split-K partial sums
+            L.raise_for(lib.inv_fc1_fwd(_ptr(feat), _ptr(self.wf), B, HID * n, K, _ptr(pre), _stream()), lib)
         extra = extra.float().contiguous()
         logits = torch.empty((B, NACT), dtype=torch.float32, device=feat.device)
         value = torch.empty((B, 1), dtype=torch.float32, device=feat.device) if n == 2 else None
         h = torch.empty((B, HID * n), dtype=torch.bfloat16, device=feat.device) if save else None
         a2 = torch.empty((B, MID * n), dtype=torch.bfloat16, device=feat.device) if save else None
         with torch.cuda.device(feat.device):
-            rc = lib.inv_heads_fwd(C.byref(self.params), _ptr(pre), _ptr(extra), _ptr(logits), _ptr(value) if n == 2 else None,
+            rc = lib.inv_heads_fwd(C.byref(self.params), _ptr(pre), slabs, _ptr(extra), _ptr(logits), _ptr(value) if n == 2 else None,
                                    _ptr(h) if save else None, _ptr(a2) if save else None, n, B, _stream())
         L.raise_for(rc, lib)
         return (logits, value, extra, h, a2) if save else (logits, value)
@@ -110,13 +121,6 @@ class HeadsOperands:
 def head_tensors(policy, actor_only=False):
     heads = [policy.fc_actor] if actor_only else [policy.fc_actor, policy.fc_critic]
     return [(s[0].weight, s[0].bias, s[2].weight, s[2].bias, s[4].weight, s[4].bias) for s in heads]
-
-
-def _split_k(B):
-    for g in (32, 16, 8, 4, 2):
-        if B % g == 0 and B // g >= 64:
-            return g
-    return 1
 
 
 class _SmallGrads:
@@ -177,21 +181,25 @@ class _HeadsTrainFn(torch.autograd.Function):
         small = _SmallGrads(dev)
         gr = small.struct()
         dpre = torch.empty((B, 2 * HID), dtype=torch.bfloat16, device=dev)
-        dpre_t = torch.empty((2 * HID, B), dtype=torch.bfloat16, device=dev) if B % 8 == 0 else None
+        # d pre^T: the K-contiguous operand of the weight-gradient kernel, rows padded to a multiple of 64 samples with zeros
+        ldt = (B + 63) // 64 * 64
+        dpre_t = (torch.empty if ldt == B else torch.zeros)((2 * HID, ldt), dtype=torch.bfloat16, device=dev)
         da2 = torch.empty((B, 2 * MID), dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
             rc = lib.inv_heads_bwd(C.byref(ops.params), _ptr(dlogits), _ptr(dvalue), _ptr(h), _ptr(a2), _ptr(extra), _ptr(dpre),
-                                   _ptr(dpre_t) if dpre_t is not None else None, _ptr(da2), C.byref(gr), B, _stream())
+                                   _ptr(dpre_t), ldt, _ptr(da2), C.byref(gr), B, _stream())
         L.raise_for(rc, lib)
         ctx.mid_state = (small, dpre, dpre_t, da2)
-        # the library's kernels for K-contiguous operands are the fast ones (tools/fc1_gemm_ab.py): both products get a transposed copy
         needs = getattr(ctx, "needs_input_grad", (True,))
         if not needs[0]:
             return None
+        # both operands of inv_fc1_dfeat are K-contiguous: d pre [B, 512] and the transposed copy of the packed weights [128 P, 512]
         wft = torch.empty((128 * P, 2 * HID), dtype=torch.bfloat16, device=dev)
+        dfeat = torch.empty((B, 128 * P), dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
             L.raise_for(lib.inv_transpose_bf16(_ptr(ops.wf), 2 * HID, 128 * P, _ptr(wft), _stream()), lib)
-        return dpre @ wft.t()                                                          # bf16 [B, 128 P]
+            L.raise_for(lib.inv_fc1_dfeat(_ptr(dpre), _ptr(wft), B, 2 * HID, 128 * P, _ptr(dfeat), _stream()), lib)
+        return dfeat                                                                   # bf16 [B, 128 P]
 
     @staticmethod
     def backward_params(ctx):
@@ -201,19 +209,16 @@ class _HeadsTrainFn(torch.autograd.Function):
         feat, extra, h, a2 = ctx.saved_tensors
         P, B, dev = ctx.pixels, feat.shape[0], feat.device
         small, dpre, dpre_t, da2 = ctx.mid_state                                        # (kept: lives as long as the context does)
-        dwf = (dpre_t if dpre_t is not None else dpre.t()) @ feat                      # bf16 [512, 128 P], f32 accumulation over B
-        gw1 = []
+        dst = getattr(ctx, "fc1_grad_out", None)                                      # direct path: the parameters' .grad themselves
+        gw1 = list(dst) if dst is not None else [torch.empty((HID, 128 * P + 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        gw2 = [torch.zeros((MID, HID), dtype=torch.float32, device=dev) for _ in range(2)]
         with torch.cuda.device(dev):
-            for i in range(2):
-                dst = getattr(ctx, "fc1_grad_out", None)                              # direct path: the parameter's .grad itself
-                g = dst[i] if dst is not None else torch.empty((HID, 128 * P + 4), dtype=torch.float32, device=dev)
-                L.raise_for(lib.inv_heads_unpack_fc1_grad(_ptr(dwf[HID * i]), C.c_void_p(small.ptr("dwe", HID * 4 * i)), HID, P, _ptr(g), _stream()), lib)
-                gw1.append(g)
-        # dW2 of both heads: split-K batched product [G][256 x B/G] x [G][B/G x 512], its two diagonal blocks are the heads'
-        G = _split_k(B)
-        part = torch.bmm(da2.view(G, B // G, 2 * MID).transpose(1, 2), h.view(G, B // G, 2 * HID))       # bf16 [G, 256, 512]
-        dw2 = part.float().sum(0)
-        gw2 = [dw2[:MID, :HID].contiguous(), dw2[MID:, HID:].contiguous()]
+            # dW1 = d pre^T @ features (stream-K, f32 segment sums in `ws`), written in the module's column order with the extra columns
+            ws = torch.empty(int(lib.inv_fc1_dw_workspace_bytes(B, 2 * HID, 128 * P)), dtype=torch.uint8, device=dev)
+            L.raise_for(lib.inv_fc1_dw(_ptr(dpre_t), _ptr(feat), C.c_void_p(small.ptr("dwe")), B, 2 * HID, P, _ptr(gw1[0]), _ptr(gw1[1]),
+                                       _ptr(ws), _stream()), lib)
+            # dW2 of both heads: d a2^T @ h, added into the zeroed buffers
+            L.raise_for(lib.inv_heads_dw2(_ptr(da2), _ptr(h), B, _ptr(gw2[0]), _ptr(gw2[1]), _stream()), lib)
         out = []
         for i in range(2):                                                             # order of head_tensors(): W1, b1, W2, b2, W3, b3
             out += [gw1[i], small.view("db1")[HID * i:HID * (i + 1)], gw2[i], small.view(f"db2_{i}"),

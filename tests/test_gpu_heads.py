@@ -36,15 +36,16 @@ def _module_heads(pol, feat, extra):
 
 
 def _emulated_heads(pol, feat, extra):
-    """The kernels' numerics in torch f32 on rounded values (bf16 weights; pre, h, a2 rounded to bf16, straight-through), so that
-    the ReLU masks are the kernels' masks: what the gradients are compared with."""
+    """The kernels' numerics in torch f32 on rounded values (bf16 weights; h, a2 rounded to bf16, straight-through; `pre` stays f32:
+    inv_fc1_fwd hands f32 partial sums to inv_heads_fwd), so that the ReLU masks are the kernels' masks: what the gradients are
+    compared with."""
     import torch
     q = lambda x: x + (x.to(torch.bfloat16).float() - x).detach()
     outs = []
     for seq in (pol.fc_actor, pol.fc_critic):
         w1 = seq[0].weight
         wf = q(w1[:, :19200].reshape(256, 128, 150).permute(0, 2, 1).reshape(256, 19200))
-        pre = q(feat @ wf.t())
+        pre = feat @ wf.t()
         h = q(torch.relu(pre + extra @ w1[:, 19200:].t() + seq[0].bias))
         a2 = q(torch.relu(h @ q(seq[2].weight).t() + seq[2].bias))
         outs.append(a2 @ q(seq[4].weight).t() + seq[4].bias)
@@ -81,19 +82,24 @@ def test_actor_only_equals_the_actor_of_both_heads_and_results_do_not_depend_on_
     with torch.no_grad():
         l2, v2 = both.forward(feat, extra)
         l1, v1 = actor.forward(feat, extra)
-        assert v1 is None and float((l1 - l2).abs().max()) < 2e-3               # the first GEMM is a narrower library call: another tiling
-        # a sample's result does not depend on where it sits in a tile: 32-row tiles of another batch (the first GEMM is the
-        # library's, so compare through the same `pre` rows: a batch that is a row-subset with the same GEMM tiling is not
-        # guaranteed -- use the kernel directly)
-        pre = feat @ both.wf.t()
+        assert v1 is None and float((l1 - l2).abs().max()) < 2e-3               # the narrower first GEMM splits K differently: another f32 summation order
+        # a sample's result does not depend on where it sits in a tile: 32-row tiles of another batch, fed the same `pre` rows
+        # (inv_fc1_fwd's slabs added in slab order, as inv_heads_fwd adds them) as ONE slab
         import ctypes as C
         from inversus_reinforcement_learning_amd import _lib as L
         lib = L.load()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        slabs = int(lib.inv_fc1_fwd_slabs(515, 512, 19200))
+        part = torch.empty((slabs, 515, 512), dtype=torch.float32, device="cuda")
+        L.raise_for(lib.inv_fc1_fwd(C.c_void_p(feat.data_ptr()), C.c_void_p(both.wf.data_ptr()), 515, 512, 19200, C.c_void_p(part.data_ptr()), st), lib)
+        pre = part[0].clone()
+        for k in range(1, slabs):
+            pre += part[k]
         sub = torch.arange(7, 515, 3, device="cuda")
         pre_s, ex_s = pre[sub].contiguous(), extra[sub].contiguous()
         lo = torch.empty((sub.numel(), 13), dtype=torch.float32, device="cuda"); va = torch.empty((sub.numel(), 1), dtype=torch.float32, device="cuda")
-        rc = lib.inv_heads_fwd(C.byref(both.params), C.c_void_p(pre_s.data_ptr()), C.c_void_p(ex_s.data_ptr()), C.c_void_p(lo.data_ptr()),
-                               C.c_void_p(va.data_ptr()), None, None, 2, sub.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = lib.inv_heads_fwd(C.byref(both.params), C.c_void_p(pre_s.data_ptr()), 1, C.c_void_p(ex_s.data_ptr()), C.c_void_p(lo.data_ptr()),
+                               C.c_void_p(va.data_ptr()), None, None, 2, sub.numel(), st)
         L.raise_for(rc, lib)
         assert torch.equal(lo, l2[sub]) and torch.equal(va, v2[sub])
 
@@ -152,18 +158,20 @@ def test_ragged_batch_leaves_rows_past_b_untouched_and_adds_into_the_gradient_bu
     gr.db3[0], gr.db3[1] = b + 4608 * 4, b + 4621 * 4
     dpre = torch.full((n + 8, 512), 7.0, dtype=torch.bfloat16, device="cuda"); da2 = torch.full((n + 8, 256), 7.0, dtype=torch.bfloat16, device="cuda")
     rc = lib.inv_heads_bwd(C.byref(ops.params), C.c_void_p(dl.data_ptr()), C.c_void_p(dv.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(a2.data_ptr()),
-                           C.c_void_p(ex.data_ptr()), C.c_void_p(dpre.data_ptr()), None, C.c_void_p(da2.data_ptr()), C.byref(gr), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                           C.c_void_p(ex.data_ptr()), C.c_void_p(dpre.data_ptr()), None, 0, C.c_void_p(da2.data_ptr()), C.byref(gr), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     L.raise_for(rc, lib)
-    # d pre^T (B % 8 == 0 only): the same numbers, transposed; a ragged last tile writes only its own columns
+    # d pre^T with a leading dimension (a multiple of 8, >= B): the same numbers, transposed; a ragged last tile writes only its own
+    # columns, the padding columns are the caller's (inv_fc1_dw wants them zero)
     n8 = 40
-    dpre8 = torch.full((n8, 512), 7.0, dtype=torch.bfloat16, device="cuda"); dpt = torch.full((512, n8), 7.0, dtype=torch.bfloat16, device="cuda")
-    args = lambda nn, t: (C.byref(ops.params), C.c_void_p(dl.data_ptr()), C.c_void_p(dv.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(a2.data_ptr()),
-                          C.c_void_p(ex.data_ptr()), C.c_void_p(dpre8.data_ptr()), C.c_void_p(t.data_ptr()), C.c_void_p(da2.data_ptr()), C.byref(gr), nn,
-                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    dpre8 = torch.full((n8, 512), 7.0, dtype=torch.bfloat16, device="cuda"); dpt = torch.full((512, 48), 7.0, dtype=torch.bfloat16, device="cuda")
+    args = lambda nn, t, ld: (C.byref(ops.params), C.c_void_p(dl.data_ptr()), C.c_void_p(dv.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(a2.data_ptr()),
+                              C.c_void_p(ex.data_ptr()), C.c_void_p(dpre8.data_ptr()), C.c_void_p(t.data_ptr()), ld, C.c_void_p(da2.data_ptr()), C.byref(gr), nn,
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
     saved_small = small.clone()
-    L.raise_for(lib.inv_heads_bwd(*args(n8, dpt)), lib)
-    assert torch.equal(dpt, dpre8.t()) and torch.equal(dpre8, dpre[:n8])
-    assert lib.inv_heads_bwd(*args(n, dpt)) == L.INV_ERR_BAD_ARG                 # 45 % 8 != 0
+    L.raise_for(lib.inv_heads_bwd(*args(n8, dpt, 48)), lib)
+    assert torch.equal(dpt[:, :n8], dpre8.t()) and bool((dpt[:, n8:] == 7).all()) and torch.equal(dpre8, dpre[:n8])
+    assert lib.inv_heads_bwd(*args(n, dpt, 40)) == L.INV_ERR_BAD_ARG             # leading dimension < B
+    assert lib.inv_heads_bwd(*args(n8, dpt, 44)) == L.INV_ERR_BAD_ARG            # not a multiple of 8 (rows must stay 16-byte aligned)
     small.copy_(saved_small)
     assert bool((dpre[n:] == 7).all()) and bool((da2[n:] == 7).all())
     # d b2 = column sums of d a2, d b1 = column sums of d pre, on top of the 1.0 that was there
@@ -175,7 +183,7 @@ def test_ragged_batch_leaves_rows_past_b_untouched_and_adds_into_the_gradient_bu
     assert float(small[4622]) == 1.0 and float(small[4623]) == 1.0
 
 
-def test_pack_fc1_and_its_gradient_are_inverse_permutations():
+def test_pack_fc1_is_the_feature_order_permutation_and_transpose_is_a_transpose():
     import ctypes as C
     import torch
     from inversus_reinforcement_learning_amd import _lib as L
@@ -185,11 +193,7 @@ def test_pack_fc1_and_its_gradient_are_inverse_permutations():
     wf, we = HD._pack_fc1([w], 150)
     want = w[:, :19200].reshape(256, 128, 150).permute(0, 2, 1).reshape(256, 19200).to(torch.bfloat16)
     assert torch.equal(wf, want) and torch.equal(we, w[:, 19200:])
-    lib = L.load()
-    g = torch.empty_like(w)
-    L.raise_for(lib.inv_heads_unpack_fc1_grad(C.c_void_p(wf.data_ptr()), C.c_void_p(we.data_ptr()), 256, 150, C.c_void_p(g.data_ptr()),
-                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), lib)
-    assert torch.equal(g[:, :19200], w[:, :19200].to(torch.bfloat16).float()) and torch.equal(g[:, 19200:], w[:, 19200:])
+    lib = L.load()                                               # (the gradient's way back is inv_fc1_dw's epilogue: tests/test_gpu_fc1.py)
     for rows, cols in ((256, 19200), (70, 130)):
         src = torch.randn(rows, cols, device="cuda").to(torch.bfloat16); dst = torch.empty((cols, rows), dtype=torch.bfloat16, device="cuda")
         L.raise_for(lib.inv_transpose_bf16(C.c_void_p(src.data_ptr()), rows, cols, C.c_void_p(dst.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), lib)
@@ -201,8 +205,8 @@ def test_bad_arguments_are_refused():
     from inversus_reinforcement_learning_amd import _lib as L
     lib = L.load()
     p = L.InvHeadsParams()
-    assert lib.inv_heads_fwd(C.byref(p), None, None, None, None, None, None, 2, 4, None) == L.INV_ERR_BAD_ARG
-    assert lib.inv_heads_fwd(C.byref(p), None, None, None, None, None, None, 3, 4, None) == L.INV_ERR_BAD_ARG
+    assert lib.inv_heads_fwd(C.byref(p), None, 1, None, None, None, None, None, 2, 4, None) == L.INV_ERR_BAD_ARG
+    assert lib.inv_heads_fwd(C.byref(p), None, 1, None, None, None, None, None, 3, 4, None) == L.INV_ERR_BAD_ARG
     lst = L.InvHeadsPackList()
     assert lib.inv_heads_pack(C.byref(lst), 9, None) == L.INV_ERR_BAD_ARG and lib.inv_heads_pack(C.byref(lst), 1, None) == L.INV_ERR_BAD_ARG
     assert lib.inv_heads_pack(C.byref(lst), 0, None) == L.INV_OK
