@@ -25,11 +25,21 @@
 // The weight gradient's `feat` operand is K-STRIDED (its rows are the contraction index): it is staged as pieces of 8 k-rows x
 // 64 columns and read with ds_read_b64_tr_b16 (the transposing LDS read), 32-byte column blocks XORed so that the eight rows of a
 // half-wave fall into eight different bank groups.
-// Work distribution: forward = split-K so that 256 workgroups exist (B = 16 384: 64 x 2 tiles x 2 K-halves; partial sums go to f32
-// slabs that inv_heads_fwd adds -- one rounding less than a bf16 `pre`); dfeat = persistent workgroups walking 4 800 tiles with the
-// DMA stream running across tile boundaries; dw = stream-K (150 tiles x 256 K-tiles dealt as 150 K-tiles per workgroup, f32
-// segment slabs summed and transposed into the module's [j][c P + p] order by k_fc1_dw_reduce).
-// The result for a sample does not depend on the batch or on its position in it (fixed K order per output element).
+// Work distribution (one 512-thread workgroup per CU: the pipeline buffers are 128 KiB of LDS):
+//   forward  split-K so that 256 workgroups exist (B = 16 384: 64 x 2 tiles x 2 K-halves); the two column tiles of a row slab and
+//            one K-half per XCD, so `feat` leaves HBM once (FETCH_SIZE 354 MB x 2 = 1.1 x its 629 MB).  The partial sums go to f32
+//            slabs that inv_heads_fwd adds in slab order -- one rounding less than a bf16 `pre`.
+//   dfeat    persistent workgroups walk the 4 800 tiles, the DMA stream runs across tile boundaries; every XCD walks its own
+//            eighth of the tile sequence (its ~10 column tiles of W stay in its L2).  The bf16 tile leaves through a 4-KB LDS window
+//            per wave as whole 128-byte rows, written through (measured: 8-byte-per-lane stores straight from the accumulator
+//            layout cost as much as the product itself -- 16 partial lines per store instruction).
+//   dw       stream-K over (column tile, K-tile) units of `feat`, 150 per workgroup pair; the two row tiles of a unit run side by
+//            side on one XCD.  f32 segment slabs, summed and transposed into the module's [j][c P + p] order by k_fc1_dw_reduce.
+// For a fixed split the result for a sample does not depend on the batch or on its position in it (fixed K order per output
+// element, no atomics: bit-identical between launches).  Measured, same-process A/B against the GEMM library on random data
+// (B = 16 384, tools/fc1_bench.py, profiles/r04_fc1_experiments.md): forward 0.27 vs 0.31 ms, dfeat 0.34 vs 0.37, dw 0.37 + 0.03
+// (reduce into the module layout) vs 0.36 + 0.04 (unpack) -- 1.2 / 0.95 / 0.87 PFLOP/s; what holds them there is written down next
+// to the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,7 +58,8 @@ constexpr int THREADS = 512;
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 16384;              // bytes of a half-tile: 128 rows x 64 k (or 64 k-rows x 128 columns) of bf16
 constexpr int BUF = 4 * HALF;            // X0 X1 W0 W1
-constexpr int LDS_BYTES = 2 * BUF;       // 128 KiB of the CU's 160
+constexpr int LDS_PIPE = 2 * BUF;        // 128 KiB of pipeline buffers
+constexpr int LDS_BYTES = LDS_PIPE + 8 * 4096;   // + a 4-KB epilogue window per wave = all 160 KiB of the CU
 
 enum { MODE_FWD = 0, MODE_DFEAT = 1, MODE_DW = 2 };
 
@@ -302,46 +313,73 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
     __builtin_amdgcn_s_barrier();
     if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
 
-    // quadrant (MH, NH) of item `it` -> memory, and its accumulators back to zero
-    auto flush = [&](const Item &it, int MH, int NH) {
-        if (MODE == MODE_DW) {
-            // stream-K segment: f32 [256 j][256 n] of this tile, row-major
-            float *o = reinterpret_cast<float *>(a.out) + (size_t)it.aux * (BM * BN) + (size_t)(wr * 128 + (lane & 15)) * BN + wc * 64 + 4 * (lane >> 4);
+    // A finished tile -> memory, accumulators back to zero.  Runs in the last MFMA segment of the item's last K-tile.
+    //   f32 outputs (split-K slabs, stream-K segments): 16 B per lane straight from the accumulator layout (4 consecutive columns).
+    //   bf16 output (dfeat, 629 MB per call): per lane only 8 B, 16 different 128-byte lines per store instruction -- measured: the
+    //   store ISSUE (line transactions), not HBM, then costs as much as the whole product.  So 32-row slices of the wave's 128 x 64
+    //   tile go through a private 4-KB LDS window (the 32 KiB the pipeline buffers leave free) and leave as whole 128-byte rows,
+    //   16 B per lane, 8 rows per store instruction.  Window image: [32 rows][128 B], 16-byte chunk ^ (row & 7), 8-byte half ^ (row >> 3 & 1):
+    //   ds_write_b64 and ds_read_b128 both conflict-free.
+    auto epilogue = [&](const Item &it) {
+        if (MODE == MODE_DFEAT) {
+            int rows = a.M - it.m0;
+            rows = rows > BM ? BM : rows;
+            const __amdgpu_buffer_rsrc_t ro = Cursor<MODE>::make_rsrc(reinterpret_cast<bf16 *>(a.out) + (size_t)it.m0 * a.ldo + it.n0, (long long)rows * a.ldo * 2);
+            lds_byte *const win = lds + LDS_PIPE + (uint32_t)wave * 4096u;
+            const int r16 = lane & 15, g = lane >> 4, rr = lane >> 3, c = lane & 7;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    *reinterpret_cast<f32x4 *>(o + (size_t)(16 * (4 * MH + mt)) * BN + 16 * (2 * NH + nt)) = acc[4 * MH + mt][2 * NH + nt];
-        } else {
-            const int mrow = it.m0 + wr * 128 + (lane & 15), ncol = it.n0 + wc * 64 + 4 * (lane >> 4);
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = mrow + 16 * (4 * MH + mt);
-                if (m < a.M) {
+                    for (int nt = 0; nt < 4; ++nt) {
+                        bf16x4 h;
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const f32x4 v = acc[4 * MH + mt][2 * NH + nt];
-                        if (MODE == MODE_FWD) {
-                            float *o = reinterpret_cast<float *>(a.out) + (size_t)it.aux * a.M * a.ldo;
-                            *reinterpret_cast<f32x4 *>(o + (size_t)m * a.ldo + ncol + 16 * (2 * NH + nt)) = v;
-                        } else {
-                            bf16x4 h;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) h[e] = (bf16)v[e];
-                            *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(a.out) + (size_t)m * a.ldo + ncol + 16 * (2 * NH + nt)) = h;
-                        }
+                        for (int e = 0; e < 4; ++e) h[e] = (bf16)acc[2 * u + mi][nt][e];
+                        const int row = 16 * mi + r16;
+                        *(__attribute__((address_space(3))) bf16x4 *)(win + row * 128 + (((2 * nt + (g >> 1)) ^ (row & 7)) * 16) + (((g & 1) ^ (r16 >> 3)) * 8)) = h;
                     }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + rr;
+                    typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+                    v4u32 v = *(const __attribute__((address_space(3))) v4u32 *)(win + row * 128 + ((c ^ (row & 7)) * 16));
+                    if (i & 1) v = v4u32{ v[2], v[3], v[0], v[1] };              // rows 8-15 / 24-31 of the window hold their 8-byte halves swapped
+                    const uint32_t off = (uint32_t)(wr * 128 + 32 * u + row) * (uint32_t)a.ldo * 2u + (uint32_t)(wc * 64 + c * 8) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 16);    // aux 16 = sc1: whole lines, written through
+                }
+            }
+        } else {
+            float *o;
+            int mrow, mlim;
+            if (MODE == MODE_DW) {
+                // stream-K segment: f32 [256 j][256 n] of this tile, row-major
+                o = reinterpret_cast<float *>(a.out) + (size_t)it.aux * (BM * BN) + wc * 64 + 4 * (lane >> 4);
+                mrow = wr * 128 + (lane & 15);
+                mlim = BM;
+            } else {
+                o = reinterpret_cast<float *>(a.out) + (size_t)it.aux * a.M * a.ldo + it.n0 + wc * 64 + 4 * (lane >> 4);
+                mrow = it.m0 + wr * 128 + (lane & 15);
+                mlim = a.M;
+            }
+            const int ld = MODE == MODE_DW ? BN : a.ldo;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int m = mrow + 16 * mt;
+                if (m < mlim) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4 *>(o + (size_t)m * ld + 16 * nt) = acc[mt][nt];
                 }
             }
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[4 * MH + mt][2 * NH + nt] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     };
+
     Item pend = cons.it;
     bool have_pend = false;
-
     bf16x8 xf[2][4], wf[2][2];
     int buf = 0;
     while (cons.valid) {
@@ -386,27 +424,27 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
         read_w(0);
         read_x(0);
         if (prod.valid) stage(prod, 1, buf ^ 1);
-        if (have_pend) flush(pend, 0, 0);
+        if (have_pend) {
+            epilogue(pend);
+            have_pend = false;
+        }
         seg();
         mma(0, 0);
         seg();
         // phase 1: (rows 0-63, columns 32-63); request W0
         read_w(1);
         if (prod.valid) stage(prod, 2, buf ^ 1);
-        if (have_pend) flush(pend, 0, 1);
         seg();
         mma(0, 1);
         seg();
         // phase 2: (rows 64-127, columns 32-63); request W1
         read_x(1);
         if (prod.valid) stage(prod, 3, buf ^ 1);
-        if (have_pend) flush(pend, 1, 1);
         seg();
         mma(1, 1);
         seg();
         // phase 3: (rows 64-127, columns 0-31); request X0 of the K-tile after next into THIS buffer (its X0 was last read in phase 2),
-        // then wait for everything but those two requests: the next K-tile is complete.  (The pending quadrant's stores go out
-        // AFTER the wait: vmcnt retires in order, younger stores do not hold it up.)
+        // then wait for everything but those two requests: the next K-tile is complete
         read_w(0);
         if (prodx.valid) {
             stage(prodx, 0, buf);
@@ -414,32 +452,27 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (have_pend) {
-            flush(pend, 1, 0);
-            have_pend = false;
-        }
         seg();
         mma(1, 0);
 
         prod.advance(a);
         prodx.advance(a);
-        // consumer: at the end of an item its tile is complete; the four quadrants leave in the load segments of the NEXT K-tile
-        // (one per phase, each right before the phase that starts the next item's sum in those registers), where they cost
-        // nothing: the partner wave of the SIMD is in its MFMA segment
+        // consumer: at the end of an item its tile is complete.  (Spreading the four quadrants' stores over the load segments of
+        // the next K-tile was measured SLOWER, 0.46 vs 0.42 ms for dfeat: vmcnt retires in order, so stores issued ahead of the
+        // K-tile's one DMA wait hold that wait up; behind it they have a whole K-tile to drain.)
         if (cons.kt + 1 == cons.it.kt1) {
-            pend = cons.it;
-            have_pend = true;
+            if (MODE == MODE_DFEAT && wr == 0) {   // group 0's epilogue moves into its NEXT load segment: beside group 1's, not before it
+                pend = cons.it;
+                have_pend = true;
+            } else {
+                epilogue(cons.it);
+            }
         }
         cons.advance(a);
         seg();
         buf ^= 1;
     }
-    if (have_pend) {
-        flush(pend, 0, 0);
-        flush(pend, 0, 1);
-        flush(pend, 1, 1);
-        flush(pend, 1, 0);
-    }
+    if (have_pend) epilogue(pend);
     if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
 #else
     (void)a;
