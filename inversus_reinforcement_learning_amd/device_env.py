@@ -275,7 +275,9 @@ class EnvShards:
     another shard's store stream (two shards of 8 192 envs: 18.6 -> 15.4 us per full 16 384-env step on a cache-resident buffer,
     25.3 -> 20.6 us streaming).  It is for callers that can consume shards independently (a double-buffered
     collector: step shard A while the policy evaluates shard B); behind a synchronous `step()` that returns every env's observation
-    the chains would run in lockstep and nothing is gained.
+    the chains would run in lockstep and nothing is gained.  Policy forwards of THIS library (FusedPolicy: trunk, inv_fc1_fwd, heads,
+    sampling) may run on several streams at once -- none of their workgroups waits on another; a GEMM-LIBRARY call on two streams at
+    once may not (stream-K kernels sized for the whole chip dead-lock each other: profiles/r04_incidents.md).
 
         shards = EnvShards(16384, 2, opponent="dummy")            # seeds: base + global index, like MultiEnvRunner
         for sh in shards:                                          # sh.batch, sh.stream, sh.offset, sh.count

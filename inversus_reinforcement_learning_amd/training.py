@@ -52,8 +52,13 @@ class RolloutCollector:
                a1 / a2 come from one batched forward of `policy` / `opponent` each (the reference
                does N batch-of-1 forwards, training.py:249-258)."""
 
-    def __init__(self, batch, agent, opponent=None, packed_obs=None, record_opponent_actions=False):
+    def __init__(self, batch, agent, opponent=None, packed_obs=None, record_opponent_actions=False, opponent_stream=False):
         self.batch, self.agent, self.opponent = batch, agent, opponent
+        # opponent_stream: the frozen opponent's forward (trunk, first Linear, heads, sampling) on a second HIP stream beside the
+        # learner's, joined before the env step.  Safe since round 4: every kernel of both forwards is this library's own and none
+        # waits on another workgroup (the library GEMM that used to sit there was a stream-K kernel sized for the whole chip, and
+        # two of those at once deadlock: profiles/r04_incidents.md).  Same actions either way; off by default (measured: no gain).
+        self._side = torch.cuda.Stream(device=batch.device) if (opponent_stream and opponent is not None) else None
         # record_opponent_actions: keep the a2 of every vector step (device tensors) so a rollout can be replayed elsewhere
         # (the parity tests replay sampled env columns through the oracle); off by default
         self.opponent_actions = [] if record_opponent_actions else None
@@ -92,8 +97,19 @@ class RolloutCollector:
         b, agent = self.batch, self.agent
         for _ in range(steps):
             grid, extra = self.obs
-            actions, log_probs, values, a1 = agent.act(grid, extra, with_u8=True)
-            a2 = self._opponent_actions() if self.selfplay else None
+            if self.selfplay and self._side is not None:
+                main = torch.cuda.current_stream(b.device)
+                self._side.wait_stream(main)                       # the P2 observations come from the previous step (main stream)
+                # host order = the one-stream collector's (learner first): the sampling kernels key their Philox streams by
+                # draws from the device generator, which advances in call order -- same actions either way
+                actions, log_probs, values, a1 = agent.act(grid, extra, with_u8=True)
+                with torch.cuda.stream(self._side):
+                    a2 = self._opponent_actions()
+                main.wait_stream(self._side)
+                a2.record_stream(main)
+            else:
+                actions, log_probs, values, a1 = agent.act(grid, extra, with_u8=True)
+                a2 = self._opponent_actions() if self.selfplay else None
             if self.opponent_actions is not None and a2 is not None:
                 self.opponent_actions.append(a2)
             # fresh obs buffers per step: the rollout buffer keeps references to them (ppo_agent.py:119)

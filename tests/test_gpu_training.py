@@ -177,3 +177,29 @@ def test_training_loop_on_the_32x32_board():
     res = training.train_vs_dummy(num_envs=8, total_steps=8 * 128, width=32, height=32, log_dir=None, seed=1, verbose=False,
                                   agent_kwargs=dict(fused_act=True, fused_update=True, batch_size=512, epochs=1))
     assert res["steps"] == 8 * 128 and all(np.isfinite(res[k]) for k in ("policy_loss", "value_loss", "entropy"))
+
+
+def test_opponent_on_a_side_stream_collects_the_same_rollout():
+    """RolloutCollector(opponent_stream=True): the frozen opponent's forward on a second HIP stream beside the learner's (both are
+    this library's kernels: no workgroup waits on another, so two concurrent forwards cannot deadlock -- profiles/r04_incidents.md).
+    Same seeds, same sampling stream order -> the same actions, rewards and observations as the one-stream collector."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    n, T = 1024, 6
+    runs = []
+    for side in (False, True):
+        torch.manual_seed(3)
+        b = DeviceEnvBatch(n, opponent="selfplay")
+        b.seed(np.arange(n, dtype=np.int64)); b.reset()
+        agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), fused_act=True)
+        opp = FusedPolicy(InversusCNNPolicy(12, 10, 15, 4).cuda().eval(), actor_only=True)
+        col = RolloutCollector(b, agent, opp, packed_obs=True, record_opponent_actions=True, opponent_stream=side)
+        col.collect(T)
+        torch.cuda.synchronize()
+        runs.append((torch.stack(agent.action_buffer), torch.stack(agent.reward_buffer), torch.stack(col.opponent_actions), col.obs[0].clone()))
+    for x, y in zip(*runs):
+        assert torch.equal(x, y)
