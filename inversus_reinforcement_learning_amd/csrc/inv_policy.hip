@@ -952,14 +952,14 @@ template <int COUT> struct BwdRegs {
 
 // The global loads of batch `bt` of a layer's pass A (x^ from HBM, LayerNorm parameters from L2).
 template <int COUT>
-__device__ __forceinline__ void bwd_request(BwdRegs<COUT> &rg, int bt, const void *ln_packed, const bf16 *xhat_n)
+__device__ __forceinline__ void bwd_request(BwdRegs<COUT> &rg, int bt, const void *ln_packed, const bf16 *xhat_n, int tid_l)
 {
     constexpr int ITEMS = BwdItems<COUT>::ITEMS, NIT = BwdItems<COUT>::NIT, CH = BwdItems<COUT>::CH;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         const int k = bt * CH + j;
         if (k < NIT) {
-            const int q = min((int)threadIdx.x + k * THREADS, ITEMS - 1);     // clamped: the tail threads re-load the last item and discard it
+            const int q = min(tid_l + k * THREADS, ITEMS - 1);     // clamped: the tail threads re-load the last item and discard it
 #ifdef POL_BWD_NO_XLOAD
             for (int e = 0; e < 8; ++e) rg.xc[k][e] = (bf16)(0.01f * (float)(q & 63));
 #else
@@ -990,6 +990,10 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
     // HBM loads issued before it -- and 20-40 more live registers put the 2 x 10-tile GEMM into scratch: 2.45-2.70 vs 1.90 ms.)
     constexpr int CH8 = COUT / 8, ITEMS = BwdItems<COUT>::ITEMS, NIT = BwdItems<COUT>::NIT, CH = BwdItems<COUT>::CH;
     constexpr int NB = (NIT + CH - 1) / CH;
+    // (hipcc hoists this thread's item addresses -- sample-invariant LayerNorm parameter pointers of all four layers -- out of the
+    // sample loop and spills 39 of those registers: 156 B/lane of scratch, written once before the loop and re-loaded once per
+    // sample OUTSIDE the GEMM loops.  Laundering `tid` per call removes the hoist: 214 VGPRs, no scratch -- and 1.89 vs 1.85 ms,
+    // the address arithmetic then runs per sample.  The spill is the cheaper form; profiles/r04_trunk_bwd_experiments.md.)
     const int tid = threadIdx.x;
     bf16x8 (&xc)[NIT] = rg.xc;                           // x^ of the thread's items
     f16x8 (&l0)[2][CH] = rg.l0, (&l1)[2][CH] = rg.l1;
@@ -997,7 +1001,7 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
     float s1 = 0.0f, s2 = 0.0f;
     bf16x8 dag[2][FROM_GLOBAL ? CH : 1];
     auto request = [&](int bt) {
-        bwd_request<COUT>(rg, bt, ln_packed, xhat_n);
+        bwd_request<COUT>(rg, bt, ln_packed, xhat_n, tid);
         if (FROM_GLOBAL) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
@@ -1082,7 +1086,7 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
     conv_gemm<CIN_T, COUT_BELOW, MW, NW>(wt, tile, lane, m0, n0, acc);
 #endif
 #if POL_BWD_EARLY
-    bwd_request<COUT_BELOW>(next, 0, next_ln, next_xhat);      // the GEMM's fragment registers are dead: first batch of the pass below
+    bwd_request<COUT_BELOW>(next, 0, next_ln, next_xhat, (int)threadIdx.x);      // the GEMM's fragment registers are dead: first batch of the pass below
     POL_PIN();
 #endif
     const int c16 = lane & 15, kg = lane >> 4;
