@@ -245,6 +245,16 @@ int  inv_policy_trunk_banded_train_fwd(const inv_policy_params *params, const vo
 int  inv_policy_band_ln_bwd(int32_t layer, int32_t height, int32_t width, const void *da_bf16, const void *z_bf16, const float *stats,
                             const void *ln_packed, void *dy_bf16 /* may be NULL */, void *dz_bf16, void *act_bf16 /* may be NULL */,
                             int32_t N, void *stream);
+/* Round 4: the same layer step in two tensor passes instead of four, with the LayerNorm parameter sums on the way (what the 32 x 32
+ * training path calls): inv_policy_band_ln_sums writes sums f32 [N][2] (sum of dx^, sum of dx^ x^ per sample: pass A of
+ * inv_policy_band_ln_bwd alone); inv_policy_band_ln_bwd2 turns (da, z, sums) into dz, the activation a = relu(LN(z)) (act may be
+ * NULL) and partial f32 [slices][2][P * C] (per slice of samples n = s, s + slices, ...: sums of dy x^ and of dy -- the output of
+ * inv_policy_band_param_grads).  dz, act and the partial sums are bit-identical to the four-pass path's. */
+int  inv_policy_band_ln_sums(int32_t layer, int32_t height, int32_t width, const void *da_bf16, const void *z_bf16, const float *stats,
+                             const void *ln_packed, float *sums, int32_t N, void *stream);
+int  inv_policy_band_ln_bwd2(int32_t layer, int32_t height, int32_t width, const void *da_bf16, const void *z_bf16, const float *stats,
+                             const void *ln_packed, const float *sums, void *dz_bf16, void *act_bf16, float *partial, int32_t slices,
+                             int32_t N, void *stream);
 int  inv_policy_band_conv_t(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,
                             const void *dz_bf16, void *da_below_bf16, int32_t N, void *stream);
 int  inv_policy_band_act(int32_t layer, int32_t height, int32_t width, const void *z_bf16, const float *stats, const void *ln_packed,

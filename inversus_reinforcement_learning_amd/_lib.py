@@ -136,6 +136,8 @@ SIGNATURES = {
     "inv_policy_obs_to_x0": (C.c_int, [_V, C.c_int32, _V, C.c_int32, _V]),
     "inv_policy_trunk_banded_train_fwd": (C.c_int, [P(InvPolicyParams), _V, C.c_int32, C.c_int32, C.c_int32, _V, P(InvPolicyBandSaved), C.c_int32, _V]),
     "inv_policy_band_ln_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, _V, _V, _V, C.c_int32, _V]),
+    "inv_policy_band_ln_sums": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, _V, C.c_int32, _V]),
+    "inv_policy_band_ln_bwd2": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, _V]),
     "inv_policy_band_conv_t": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_band_act": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_band_wgrad": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),

@@ -1672,6 +1672,134 @@ __global__ __launch_bounds__(THREADS) void k_band_ln_bwd(const bf16 *__restrict_
     }
 }
 
+
+// Round 4: the LayerNorm backward of a banded layer in TWO tensor passes over (da, z) instead of four, and the parameter sums with it:
+//   k_band_ln_sums   pass A alone: per sample the sums of dx^ = da [x^ w + b > 0] w and of dx^ x^ (the same expressions, the same
+//                    summation order as k_band_ln_bwd's pass A), written to sums [N][2]
+//   k_band_ln_bwd2   ONE pass that turns (da, z, the sample's two sums) into dz AND the activation a = relu(x^ w + b) AND the layer's
+//                    LayerNorm weight / bias gradient partial sums.  It is cut like k_band_param_grads, not like k_band_ln_bwd: a thread
+//                    owns the same 8 channels of one pixel for EVERY sample of its slice (gridDim.y slices), so its LayerNorm
+//                    parameters are loaded once, its parameter sums stay in registers, and the sample's scalars (rstd, shift, the two
+//                    means) are wave-uniform loads; all tensor accesses are 16 B per thread, consecutive threads consecutive items.
+// Per layer: 2 + 2 tensor reads and 2 writes instead of 2 + 2 + 2 reads and 2 writes (k_band_ln_bwd + k_band_param_grads); dz, the
+// activation and the partial sums are bit-identical to the old path's.
+template <int C>
+__global__ __launch_bounds__(THREADS) void k_band_ln_sums(const bf16 *__restrict__ da, const bf16 *__restrict__ z, const float *__restrict__ stats,
+                                                           int layer, const void *__restrict__ ln_packed, float *__restrict__ sums, int pixels, int N)
+{
+    __shared__ float red[2 * WAVES];
+    constexpr int CH = 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int items = pixels * (C / 8);
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        const float rstd = stats[(size_t)n * 8 + 2 * layer], shift = stats[(size_t)n * 8 + 2 * layer + 1];
+        const bf16x8 *da8 = reinterpret_cast<const bf16x8 *>(da + (size_t)n * pixels * C);
+        const bf16x8 *z8 = reinterpret_cast<const bf16x8 *>(z + (size_t)n * pixels * C);
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 1
+        for (int q0 = tid; q0 < items; q0 += CH * THREADS) {
+            bf16x8 a[CH], zz[CH];
+            f16x8 l0[CH], l1[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int q = min(q0 + j * THREADS, items - 1);
+                a[j] = da8[q]; zz[j] = z8[q];
+                const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;
+                l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+                l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+            }
+            POL_PIN();
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int q = q0 + j * THREADS;
+                if (q < items) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float g = (float)(e < 4 ? l0[j][e] : l1[j][e - 4]), bb = (float)(e < 4 ? l0[j][4 + e] : l1[j][e]);
+                        const float xh = fmaf((float)zz[j][e], rstd, shift);
+                        const float pre = fmaf(xh, g, bb);
+                        const float dxh = pre > 0.0f ? (float)a[j][e] * g : 0.0f;
+                        s1 += dxh;
+                        s2 = fmaf(dxh, xh, s2);
+                    }
+                }
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { red[wave] = s1; red[WAVES + wave] = s2; }
+        __syncthreads();
+        if (tid == 0) {
+            float S1 = 0.0f, S2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { S1 += red[w]; S2 += red[WAVES + w]; }
+            sums[(size_t)n * 2] = S1;
+            sums[(size_t)n * 2 + 1] = S2;
+        }
+        __syncthreads();
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_band_ln_bwd2(const bf16 *__restrict__ da, const bf16 *__restrict__ z, const float *__restrict__ stats,
+                                                       int layer, const void *__restrict__ ln_packed, const float *__restrict__ sums,
+                                                       bf16 *__restrict__ dz, bf16 *__restrict__ act, float *__restrict__ part, int E8, int N)
+{
+    const int e8 = blockIdx.x * 256 + threadIdx.x;
+    if (e8 >= E8) return;
+    float aw[8], ab[8], g[8], bb[8];
+    {
+        const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)e8 * 16;
+        const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            aw[j] = ab[j] = 0.0f;
+            g[j] = (float)(j < 4 ? l0[j] : l1[j - 4]);
+            bb[j] = (float)(j < 4 ? l0[4 + j] : l1[j]);
+        }
+    }
+    const size_t stride = (size_t)E8 * 8;
+    const float inv_cnt = 1.0f / (float)stride;                           // C * pixels elements per sample
+    constexpr int U = 4;                                                  // samples in flight per thread
+    for (int n0 = blockIdx.y; n0 < N; n0 += U * gridDim.y) {
+        bf16x8 d[U], zz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = min(n0 + u * (int)gridDim.y, N - 1);             // the tail re-loads the last sample and discards it
+            const size_t o = (size_t)n * stride + (size_t)e8 * 8;
+            d[u] = *reinterpret_cast<const bf16x8 *>(da + o);
+            zz[u] = *reinterpret_cast<const bf16x8 *>(z + o);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = n0 + u * (int)gridDim.y;
+            if (n < N) {
+                const float rstd = stats[(size_t)n * 8 + 2 * layer], shift = stats[(size_t)n * 8 + 2 * layer + 1];
+                const float m1 = sums[(size_t)n * 2] * inv_cnt, m2 = sums[(size_t)n * 2 + 1] * inv_cnt;
+                bf16x8 o, av;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = fmaf((float)zz[u][j], rstd, shift);
+                    const float pre = fmaf(xh, g[j], bb[j]);
+                    av[j] = (bf16)fmaxf(pre, 0.0f);
+                    const float df = pre > 0.0f ? (float)d[u][j] : 0.0f;
+                    o[j] = (bf16)(rstd * (df * g[j] - m1 - xh * m2));
+                    aw[j] = fmaf(df, xh, aw[j]);
+                    ab[j] += df;
+                }
+                const size_t off = (size_t)n * stride + (size_t)e8 * 8;
+                *reinterpret_cast<bf16x8 *>(dz + off) = o;
+                if (act) *reinterpret_cast<bf16x8 *>(act + off) = av;
+            }
+        }
+    }
+    float *o = part + (size_t)blockIdx.y * 2 * stride + (size_t)e8 * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(aw[0], aw[1], aw[2], aw[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(aw[4], aw[5], aw[6], aw[7]);
+    *reinterpret_cast<float4 *>(o + stride) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+    *reinterpret_cast<float4 *>(o + stride + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
+}
+
 // raw band loader: tile <- the band's R + 2 rows of a channels-last tensor [P][CSRC], zeros outside the board
 template <class G, int R, int CSRC>
 __device__ __forceinline__ void band_load_raw(bf16 *tile, const bf16 *__restrict__ src, int band)
@@ -1984,6 +2112,40 @@ extern "C" int inv_policy_band_ln_bwd(int32_t layer, int32_t height, int32_t wid
     if (kBandC[layer] == 32) INV_LNB(32); else if (kBandC[layer] == 64) INV_LNB(64); else INV_LNB(128);
 #undef INV_LNB
     return launch_status("inv_policy_band_ln_bwd");
+}
+
+
+extern "C" int inv_policy_band_ln_sums(int32_t layer, int32_t height, int32_t width, const void *da_bf16, const void *z_bf16, const float *stats,
+                                       const void *ln_packed, float *sums, int32_t N, void *stream)
+{
+    if (!da_bf16 || !z_bf16 || !stats || !ln_packed || !sums || N < 0 || layer < 0 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_ln_sums: NULL tensor, N < 0 or layer outside 0..3");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_ln_sums: built for the 32 x 32 board");
+    if (N == 0) return INV_OK;
+    const int pixels = height * width, grid = N < 4 * inv_cu_count() ? N : 4 * inv_cu_count();
+    using pol::bf16;
+#define INV_LNS(C_) hipLaunchKernelGGL((pol::k_band_ln_sums<C_>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, reinterpret_cast<const bf16 *>(da_bf16), \
+        reinterpret_cast<const bf16 *>(z_bf16), stats, (int)layer, ln_packed, sums, pixels, (int)N)
+    if (kBandC[layer] == 32) INV_LNS(32); else if (kBandC[layer] == 64) INV_LNS(64); else INV_LNS(128);
+#undef INV_LNS
+    return launch_status("inv_policy_band_ln_sums");
+}
+
+extern "C" int inv_policy_band_ln_bwd2(int32_t layer, int32_t height, int32_t width, const void *da_bf16, const void *z_bf16, const float *stats,
+                                       const void *ln_packed, const float *sums, void *dz_bf16, void *act_bf16, float *partial, int32_t slices,
+                                       int32_t N, void *stream)
+{
+    if (!da_bf16 || !z_bf16 || !stats || !ln_packed || !sums || !dz_bf16 || !partial || N < 0 || slices < 1 || layer < 0 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_ln_bwd2: NULL tensor, N < 0, slices < 1 or layer outside 0..3 (act may be NULL)");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_ln_bwd2: built for the 32 x 32 board");
+    const int e8 = height * width * kBandC[layer] / 8, bx = (e8 + 255) / 256;
+    using pol::bf16;
+#define INV_LNB2(C_) hipLaunchKernelGGL((pol::k_band_ln_bwd2<C_>), dim3(bx, slices), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16 *>(da_bf16), \
+        reinterpret_cast<const bf16 *>(z_bf16), stats, (int)layer, ln_packed, sums, reinterpret_cast<bf16 *>(dz_bf16), reinterpret_cast<bf16 *>(act_bf16), \
+        partial, e8, (int)N)
+    if (kBandC[layer] == 32) INV_LNB2(32); else if (kBandC[layer] == 64) INV_LNB2(64); else INV_LNB2(128);
+#undef INV_LNB2
+    return launch_status("inv_policy_band_ln_bwd2");
 }
 
 extern "C" int inv_policy_band_conv_t(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,

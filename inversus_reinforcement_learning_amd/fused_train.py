@@ -274,22 +274,24 @@ class _TrunkTrainBandedFn(torch.autograd.Function):
             grads[4 * l] = dw[:, :, :cin].reshape(c, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
             grads[4 * l + 1] = db
 
-        # l = 3 .. 0:  ln_bwd(l) [da_l, z_l -> dz_l, and a_l for the weight gradient of the layer above]  ->  wgrad(l + 1) [a_l, dz_{l+1}]
-        #              ->  LayerNorm sums(l) [da_l, z_l]  ->  conv_t(l) [dz_l -> da_{l-1}];  finally wgrad(0) [x0, dz_0]
+        # l = 3 .. 0:  ln_sums(l) [da_l, z_l -> the sample's two sums]  ->  ln_bwd2(l) [da_l, z_l -> dz_l, a_l, LayerNorm parameter sums]
+        #              ->  wgrad(l + 1) [a_l, dz_{l+1}]  ->  conv_t(l) [dz_l -> da_{l-1}];  finally wgrad(0) [x0, dz_0]
         with torch.cuda.device(dev):
             dz_above = None
             for l in (3, 2, 1, 0):
                 c = _COUT[l]
                 dz = torch.empty_like(z[l])
                 act = torch.empty_like(z[l]) if l < 3 else None
-                L.raise_for(lib.inv_policy_band_ln_bwd(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), None, _ptr(dz),
-                                                       _ptr(act) if act is not None else None, n, st()), lib)
+                # two tensor passes over (da, z): the sample's two sums, then dz + activation + LayerNorm parameter partial sums in one
+                sums = torch.empty((n, 2), dtype=torch.float32, device=dev)
+                L.raise_for(lib.inv_policy_band_ln_sums(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(sums), n, st()), lib)
+                slices = max(1, min(n, _RED_SLICES))
+                part = torch.empty((slices, 2, pix, c), dtype=torch.float32, device=dev)
+                L.raise_for(lib.inv_policy_band_ln_bwd2(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(sums), _ptr(dz),
+                                                        _ptr(act) if act is not None else None, _ptr(part), slices, n, st()), lib)
                 if l < 3:
                     wgrad(l + 1, act, dz_above)
                     del act, dz_above
-                slices = max(1, min(n, _RED_SLICES))
-                part = torch.empty((slices, 2, pix, c), dtype=torch.float32, device=dev)
-                L.raise_for(lib.inv_policy_band_param_grads(l, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(part), slices, pix * c, n, st()), lib)
                 red = part.sum(dim=0)
                 grads[4 * l + 2], grads[4 * l + 3] = red[0].t().reshape(c, hb, wb), red[1].t().reshape(c, hb, wb)
                 del part

@@ -139,6 +139,17 @@ def test_band_ln_bwd_act_and_param_grads_match_autograd(layer):
     L.raise_for(lib.inv_policy_band_param_grads(layer, _p(da), _p(z), _p(stats), _p(ln), _p(part), 4, P * c, n, _st()), lib)
     red = part.sum(0)
     assert rel(red[0], wcl.grad) < 3e-3 and rel(red[1], bcl.grad) < 3e-3, (rel(red[0], wcl.grad), rel(red[1], bcl.grad))
+    # round 4: the two-pass form (sample sums, then dz + activation + parameter sums in ONE pass) is the four-pass form bit for bit
+    sums = torch.full((n, 2), float("nan"), device="cuda")
+    L.raise_for(lib.inv_policy_band_ln_sums(layer, H, W, _p(da), _p(z), _p(stats), _p(ln), _p(sums), n, _st()), lib)
+    dz3, act3 = torch.full_like(z, 7.0), torch.full_like(z, 7.0)
+    part3 = torch.full((4, 2, P, c), float("nan"), device="cuda")
+    L.raise_for(lib.inv_policy_band_ln_bwd2(layer, H, W, _p(da), _p(z), _p(stats), _p(ln), _p(sums), _p(dz3), _p(act3), _p(part3), 4, n, _st()), lib)
+    assert torch.equal(dz3, dz) and torch.equal(act3, act_k) and torch.equal(part3, part)
+    dz4 = torch.empty_like(z)                                              # act is optional; more slices than samples leave zero partials
+    part4 = torch.full((8, 2, P, c), float("nan"), device="cuda")
+    L.raise_for(lib.inv_policy_band_ln_bwd2(layer, H, W, _p(da), _p(z), _p(stats), _p(ln), _p(sums), _p(dz4), None, _p(part4), 8, n, _st()), lib)
+    assert torch.equal(dz4, dz) and bool((part4[n:] == 0).all()) and rel(part4.sum(0), red) < 1e-6
 
 
 @pytest.mark.parametrize("n", [3, 40])
