@@ -42,9 +42,14 @@
 // to the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/inversus_hip.h"
 #include "inv_internal.h"
+
+#ifndef FC1_KNOCK
+#define FC1_KNOCK 0                       // tools-only timing probes (wrong results on purpose): 1 no fragment reads, 2 no DMA, 3 neither
+#endif
 
 namespace fc1 {
 
@@ -210,7 +215,7 @@ struct Cursor {
     }
 };
 
-template <int MODE, bool STAGGER>
+template <int MODE, int SCHED>
 __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (it cannot instantiate a body built on buffer descriptors)
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
     const int wr = wave >> 2, wc = wave & 3;
     constexpr bool WT = MODE == MODE_DW;                 // W operand K-strided: transposing reads
+    constexpr bool STAGGER = true;
 
     // ---- staging: piece pc = 8 j + wave (j = 0, 1) of a half-tile
     //   K-contiguous operand: piece = rows 8 pc .. 8 pc + 7, this lane: row 8 pc + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
@@ -236,6 +242,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
         } else {
             vw[j] = (uint32_t)r * (uint32_t)a.ldw * 2u + (uint32_t)c * 16u;
         }
+    }
+    uint32_t vxo[4];                                     // SCHED 2: the wave's four pieces of ITS group's X half-tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int pc = 4 * j + (wave & 3), r = 8 * pc + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        vxo[j] = (uint32_t)(r + 128 * wr) * (uint32_t)a.ldx * 2u + (uint32_t)c * 16u;
     }
     const uint32_t xhalf = 128u * (uint32_t)a.ldx * 2u;                      // second half-tile: 128 rows further
     const uint32_t whalf = WT ? 256u : 128u * (uint32_t)a.ldw * 2u;         // WT: 128 columns further
@@ -296,6 +308,23 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
         }
     };
 
+    auto stage_x_own = [&](const Cursor<MODE> &c, int buf) {
+        const uint32_t d = (uint32_t)(wave & 3) * 1024u + (uint32_t)wr * HALF + (uint32_t)buf * BUF, so = (uint32_t)c.kt * 128u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rx, (__attribute__((address_space(3))) void *)(lds + d + 4096u * j), 16, vxo[j], so, 0, 0);
+    };
+
+    if (SCHED == 2) {
+        // ---- prologue: K-tile 0 complete
+        stage(prod, 2, 0);
+        stage(prod, 3, 0);
+        stage_x_own(prod, 0);
+        prod.advance(a);                      // -> K-tile 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+    } else {
     // ---- prologue: K-tile 0 complete, X0 of K-tile 1 in flight
     stage(prod, 0, 0);
     stage(prod, 1, 0);
@@ -312,6 +341,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
     prodx.advance(a);                         // -> K-tile 2
     __builtin_amdgcn_s_barrier();
     if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+    }
 
     // A finished tile -> memory, accumulators back to zero.  Runs in the last MFMA segment of the item's last K-tile.
     //   f32 outputs (split-K slabs, stream-K segments): 16 B per lane straight from the accumulator layout (4 consecutive columns).
@@ -380,7 +410,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
 
     Item pend = cons.it;
     bool have_pend = false;
-    bf16x8 xf[2][4], wf[2][2];
+    bf16x8 xf[2][4], wf[2][SCHED == 2 ? 4 : 2];
     int buf = 0;
     while (cons.valid) {
         const lds_byte *const lb = lds + (uint32_t)buf * BUF;
@@ -419,6 +449,64 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
+        if (SCHED == 2) {
+            // TWO phases of 32 MFMAs per K-tile (half the segment boundaries of the four-phase form).  Phase 0: all of W's fragments
+            // (both column halves stay in registers for the K-tile) + rows 0-63 of X, and ALL DMA requests of the next K-tile:
+            // W's two half-tiles (every wave its share) and the group's OWN X half-tile (X rows 0-127 are only ever read by waves
+            // 0-3, rows 128-255 by waves 4-7, so the group that read a half-tile last is the one that re-fills it).  Phase 1: rows
+            // 64-127 of X.  Waits: W (read by both groups at the next phase 0) in phase 1's load segment, leaving the four X requests
+            // in flight; X after the K-tile's last MFMA.  Hazards (group 0 loads in segments 4 t, 4 t + 2; group 1 one later):
+            //   W slots of K-tile t-1: last read in segments 4 t - 4 / 4 t - 3, re-filled from segment 4 t on;
+            //   X slot of group h: last read in its segment 4 t - 2 + h, re-filled by the same group in its segment 4 t + h;
+            //   W of K-tile t + 1: waited in segments 4 t + 2 / 4 t + 3, first read in 4 t + 4;  X: waited at the end of the group's
+            //   last MFMA segment, first read by the same group one barrier later.
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if ((FC1_KNOCK & 1) && cons.kt != cons.it.kt0) break;          // probe: fragments stay what the first K-tile loaded
+                if (WT) {
+                    wf[0][nt] = tr_frag(lb + wt_lo[0][nt], lb + wt_hi[0][nt]);
+                    wf[1][nt] = tr_frag(lb + wt_lo[1][nt], lb + wt_hi[1][nt]);
+                } else {
+                    wf[0][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + wb0 + (uint32_t)nt * 2048u);
+                    wf[1][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + wb1 + (uint32_t)nt * 2048u);
+                }
+            }
+            if (!(FC1_KNOCK & 1) || cons.kt == cons.it.kt0) read_x(0);
+            if (prod.valid && !(FC1_KNOCK & 2)) {
+                stage(prod, 2, buf ^ 1);
+                stage(prod, 3, buf ^ 1);
+                stage_x_own(prod, buf ^ 1);
+            }
+            seg();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma(wf[ks][nt], xf[ks][mt], acc[mt][nt]);
+            __builtin_amdgcn_s_setprio(0);
+            seg();
+            if (!(FC1_KNOCK & 1) || cons.kt == cons.it.kt0) read_x(1);
+            if (prod.valid && !(FC1_KNOCK & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            seg();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[4 + mt][nt] = mfma(wf[ks][nt], xf[ks][mt], acc[4 + mt][nt]);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prod.advance(a);
+            if (cons.kt + 1 == cons.it.kt1) epilogue(cons.it);
+            cons.advance(a);
+            seg();
+            buf ^= 1;
+            continue;
+        }
 
         // phase 0: quadrant (rows 0-63, columns 0-31); request X1 of the next K-tile
         read_w(0);
@@ -541,11 +629,14 @@ static int fc1_launch(const fc1::Args &a, int grid, hipStream_t st, const char *
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     if (!attr_done[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
         if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "%s: hipFuncSetAttribute(%d B of LDS): %s", what, fc1::LDS_BYTES, hipGetErrorString(e));
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((fc1::k_fc1_gemm<MODE, true>), dim3(grid), dim3(fc1::THREADS), fc1::LDS_BYTES, st, a);
+    const char *sch = getenv("INV_FC1_SCHED");                                  // EXPERIMENT: 4 = the four-phase schedule
+    if (sch && sch[0] == '4') hipLaunchKernelGGL((fc1::k_fc1_gemm<MODE, 4>), dim3(grid), dim3(fc1::THREADS), fc1::LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((fc1::k_fc1_gemm<MODE, 2>), dim3(grid), dim3(fc1::THREADS), fc1::LDS_BYTES, st, a);
     return fc1_status(what);
 }
 
