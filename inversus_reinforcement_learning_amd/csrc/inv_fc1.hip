@@ -42,13 +42,15 @@
 // to the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/inversus_hip.h"
 #include "inv_internal.h"
 
+#if defined(FC1_KNOCK) && !defined(INV_TOOLS_BUILD)
+#error "FC1_KNOCK builds compute wrong results on purpose: tools/build_variant.py only (it defines INV_TOOLS_BUILD)"
+#endif
 #ifndef FC1_KNOCK
-#define FC1_KNOCK 0                       // tools-only timing probes (wrong results on purpose): 1 no fragment reads, 2 no DMA, 3 neither
+#define FC1_KNOCK 0                       // tools-only timing probes (wrong results on purpose): 1 no fragment reads, 2 no DMA requests, 4 requests through zero-record descriptors (issued, dropped by the range check)
 #endif
 
 namespace fc1 {
@@ -61,10 +63,8 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
 constexpr int THREADS = 512;
 constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int HALF = 16384;              // bytes of a half-tile: 128 rows x 64 k (or 64 k-rows x 128 columns) of bf16
-constexpr int BUF = 4 * HALF;            // X0 X1 W0 W1
-constexpr int LDS_PIPE = 2 * BUF;        // 128 KiB of pipeline buffers
-constexpr int LDS_BYTES = LDS_PIPE + 8 * 4096;   // + a 4-KB epilogue window per wave = all 160 KiB of the CU
+[[maybe_unused]] constexpr int HALF = 16384;              // bytes of a half-tile: 128 rows x 64 k (or 64 k-rows x 128 columns) of bf16
+constexpr int LDS_BYTES = 163840;         // all 160 KiB of the CU (the map is above the kernel)
 
 enum { MODE_FWD = 0, MODE_DFEAT = 1, MODE_DW = 2 };
 
@@ -174,7 +174,7 @@ struct Cursor {
     {
         const uint64_t b = (uint64_t)base;
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-        const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes)));
+        const uint32_t n = (FC1_KNOCK & 4) ? 0u : __builtin_amdgcn_readfirstlane((uint32_t)(bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes)));
         return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)n, 0x00020000);
     }
     __device__ __forceinline__ void bind(const Args &a)
@@ -215,7 +215,12 @@ struct Cursor {
     }
 };
 
-template <int MODE, int SCHED>
+// LDS map (bytes).  X buffers: 32 KiB * (t & 1), rows 0-127 | 128-255 of the tile.  W buffers behind them at 64 KiB:
+//   W3 (forward, weight gradient): THREE of 32 KiB, K-tile t in buffer t % 3 -- all 160 KiB;
+//   otherwise (dfeat):             two, K-tile t in buffer t & 1, and a 4-KiB epilogue window per wave behind them.
+[[maybe_unused]] constexpr int LDS_X = 32768, LDS_W0 = 65536, LDS_W = 32768, LDS_WIN = LDS_W0 + 2 * LDS_W;
+
+template <int MODE>
 __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass only needs the launch stub (it cannot instantiate a body built on buffer descriptors)
@@ -223,19 +228,20 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
     lds_byte *const lds = (lds_byte *)lds_raw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave >> 2, wc = wave & 3;             // wr = the wave's GROUP: rows 128 wr .. + 127 of the tile; columns 64 wc .. + 63
     constexpr bool WT = MODE == MODE_DW;                 // W operand K-strided: transposing reads
-    constexpr bool STAGGER = true;
+    constexpr bool W3 = MODE != MODE_DFEAT;              // three W buffers + balanced requests; dfeat: two + the epilogue window
 
-    // ---- staging: piece pc = 8 j + wave (j = 0, 1) of a half-tile
-    //   K-contiguous operand: piece = rows 8 pc .. 8 pc + 7, this lane: row 8 pc + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
+    // ---- DMA source offsets.  A half-tile is 16 pieces of 1 KiB (one wave-instruction each):
+    //   K-contiguous operand: piece pc = rows 8 pc .. 8 pc + 7; this lane: row 8 pc + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
     //   K-strided operand (WT): the half-tile is [64 k-rows][128 columns]; piece = (k-block kb = pc >> 1 of 8 rows, column half pc & 1):
     //   lane: k-row 8 kb + (lane >> 3), 16-byte chunk (lane & 7) ^ (2 * f), f = ((kb & 1) << 1) | ((row >> 1) & 1)  (32-byte blocks swap)
-    uint32_t vx[2], vw[2];
+    // W (read by both groups): every wave requests pieces 8 j + wave (j = 0, 1) of both half-tiles.  X rows 0-127 are only ever read by
+    // waves 0-3 and rows 128-255 by waves 4-7, so a group requests ALL of its own half-tile: pieces 4 j + (wave & 3), j = 0..3.
+    uint32_t vw[2], vx[4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pc = 8 * j + wave, r = 8 * pc + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-        vx[j] = (uint32_t)r * (uint32_t)a.ldx * 2u + (uint32_t)c * 16u;
         if (WT) {
             const int kb = pc >> 1, ch = pc & 1, kr = 8 * kb + (lane >> 3), f = ((kb & 1) << 1) | ((kr >> 1) & 1);
             vw[j] = (uint32_t)kr * (uint32_t)a.ldw * 2u + (uint32_t)ch * 128u + (uint32_t)((lane & 7) ^ (2 * f)) * 16u;
@@ -243,27 +249,23 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
             vw[j] = (uint32_t)r * (uint32_t)a.ldw * 2u + (uint32_t)c * 16u;
         }
     }
-    uint32_t vxo[4];                                     // SCHED 2: the wave's four pieces of ITS group's X half-tile
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int pc = 4 * j + (wave & 3), r = 8 * pc + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-        vxo[j] = (uint32_t)(r + 128 * wr) * (uint32_t)a.ldx * 2u + (uint32_t)c * 16u;
+        vx[j] = (uint32_t)(r + 128 * wr) * (uint32_t)a.ldx * 2u + (uint32_t)c * 16u;
     }
-    const uint32_t xhalf = 128u * (uint32_t)a.ldx * 2u;                      // second half-tile: 128 rows further
-    const uint32_t whalf = WT ? 256u : 128u * (uint32_t)a.ldw * 2u;         // WT: 128 columns further
-    const uint32_t dst0 = (uint32_t)wave * 1024u;                            // + 8192 j + HALF * slot + BUF * buffer
+    const uint32_t whalf = WT ? 256u : 128u * (uint32_t)a.ldw * 2u;         // second W half-tile: 128 rows (WT: 128 columns) further
 
-    // ---- fragment read bases (bytes inside a buffer)
+    // ---- fragment read offsets inside an X / W buffer
     //   K-contiguous: row r = 16 T + (lane & 15) of the half-tile, chunk 4 ks + (lane >> 4):
     //     (r >> 3) * 1024 + (r & 7) * 128 + ((chunk ^ ((r >> 1) & 7)) * 16)  ->  T * 2048 + lanepart(ks)
     const uint32_t lp0 = (uint32_t)(((lane >> 3) & 1) * 1024 + (lane & 7) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) * 16));
     const uint32_t xb0 = (uint32_t)wr * HALF + lp0, xb1 = xb0 ^ 64u;
-    const uint32_t wb0 = 2u * HALF + (uint32_t)(wc >> 1) * HALF + (uint32_t)(wc & 1) * 4u * 2048u + lp0, wb1 = wb0 ^ 64u;
+    const uint32_t wb0 = (uint32_t)(wc >> 1) * HALF + (uint32_t)(wc & 1) * 4u * 2048u + lp0, wb1 = wb0 ^ 64u;
     //   K-strided (WT): half-tile (wc >> 1) = columns 128 (wc >> 1) .. + 127 of the tile; the wave's 64 columns = column half
     //   ch = wc & 1 of every k-block.  Fragment (column tile T of 16, k-step ks): lane 4 q + p of 16-lane group g reads k-row
-    //   8 g + q (lo) / 8 g + 4 + q (hi) of k-block kb = 4 ks + g, columns 16 T + 4 p .. + 3:
-    //     piece (2 kb + ch) * 1024 + krow * 128 + ((2 (T & 3)... the wave's 64 columns are ONE column half: 32-byte block cb = T (0..3)
-    //     byte = cb' * 32 + p * 8, cb' = cb ^ f(kb, krow)
+    //   8 g + q (lo) / 8 g + 4 + q (hi) of k-block kb = 4 ks + g, columns 16 T + 4 p .. + 3: piece (2 kb + ch), byte
+    //   krow * 128 + (T ^ f(kb, krow)) * 32 + p * 8
     uint32_t wt_lo[2][4], wt_hi[2][4];
     if (WT) {
         const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
             for (int T = 0; T < 4; ++T) {
                 const int kb = 4 * ks + g;
                 const int flo = ((kb & 1) << 1) | ((q >> 1) & 1), fhi = ((kb & 1) << 1) | (((4 + q) >> 1) & 1);
-                const uint32_t pbase = 2u * HALF + (uint32_t)(wc >> 1) * HALF + (uint32_t)(2 * kb + (wc & 1)) * 1024u;
+                const uint32_t pbase = (uint32_t)(wc >> 1) * HALF + (uint32_t)(2 * kb + (wc & 1)) * 1024u;
                 wt_lo[ks][T] = pbase + (uint32_t)(q * 128 + ((T ^ flo) * 32) + p * 8);
                 wt_hi[ks][T] = pbase + (uint32_t)((4 + q) * 128 + ((T ^ fhi) * 32) + p * 8);
             }
@@ -285,77 +287,66 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
-    Cursor<MODE> cons, prod, prodx;          // consumer; producer of X1 / W0 / W1 (one K-tile ahead) and of X0 (two ahead)
+    // cursors: the consumer (K-tile t), the X producer (t + 1) and the W producer (W3: t + 2; else t + 1)
+    Cursor<MODE> cons, px, pw;
     cons.start(a);
-    prod = cons;
-    prodx = cons;
+    px = cons;
+    pw = cons;
 
-    // slot: 0 X0, 1 X1, 2 W0, 3 W1
-    auto stage = [&](const Cursor<MODE> &c, int slot, int buf) {
-        const uint32_t d = dst0 + (uint32_t)slot * HALF + (uint32_t)buf * BUF;
-        if (slot < 2) {
-            const uint32_t so = (uint32_t)c.kt * 128u;
+    auto req_w = [&](const Cursor<MODE> &c, int wslot) {                     // both half-tiles of W, this wave's share: 4 requests
+        const uint32_t so = WT ? 0u : (uint32_t)c.kt * 128u;                  // WT: the descriptor itself walks down the rows
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rx, (__attribute__((address_space(3))) void *)(lds + d + 8192u * j), 16,
-                                                         vx[j] + (slot == 1 ? xhalf : 0u), so, 0, 0);
-        } else {
-            const uint32_t so = WT ? 0u : (uint32_t)c.kt * 128u;                  // WT: the descriptor itself walks down the rows
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rw, (__attribute__((address_space(3))) void *)(lds + d + 8192u * j), 16,
-                                                         vw[j] + (slot == 3 ? whalf : 0u), so, 0, 0);
-        }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rw, (__attribute__((address_space(3))) void *)(lds + LDS_W0 + (uint32_t)wslot * LDS_W + (uint32_t)h * HALF +
+                                                                                                        (uint32_t)wave * 1024u + 8192u * j),
+                                                         16, vw[j] + (h ? whalf : 0u), so, 0, 0);
     };
-
-    auto stage_x_own = [&](const Cursor<MODE> &c, int buf) {
-        const uint32_t d = (uint32_t)(wave & 3) * 1024u + (uint32_t)wr * HALF + (uint32_t)buf * BUF, so = (uint32_t)c.kt * 128u;
+    auto req_x = [&](const Cursor<MODE> &c, int xslot) {                     // the group's own X half-tile: 4 requests
+        const uint32_t d = (uint32_t)xslot * LDS_X + (uint32_t)wr * HALF + (uint32_t)(wave & 3) * 1024u, so = (uint32_t)c.kt * 128u;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rx, (__attribute__((address_space(3))) void *)(lds + d + 4096u * j), 16, vxo[j], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rx, (__attribute__((address_space(3))) void *)(lds + d + 4096u * j), 16, vx[j], so, 0, 0);
+    };
+    auto seg = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     };
 
-    if (SCHED == 2) {
-        // ---- prologue: K-tile 0 complete
-        stage(prod, 2, 0);
-        stage(prod, 3, 0);
-        stage_x_own(prod, 0);
-        prod.advance(a);                      // -> K-tile 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
-    } else {
-    // ---- prologue: K-tile 0 complete, X0 of K-tile 1 in flight
-    stage(prod, 0, 0);
-    stage(prod, 1, 0);
-    stage(prod, 2, 0);
-    stage(prod, 3, 0);
-    prod.advance(a);                          // -> K-tile 1
-    prodx.advance(a);
-    if (prodx.valid) {
-        stage(prodx, 0, 1);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // ---- prologue: K-tile 0 complete (W3: W of K-tile 1 in flight)
+    req_x(px, 0);
+    req_w(pw, 0);
+    px.advance(a);
+    pw.advance(a);
+    if (W3) {
+        if (pw.valid && !(FC1_KNOCK & 2)) {
+            req_w(pw, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        pw.advance(a);
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    prodx.advance(a);                         // -> K-tile 2
     __builtin_amdgcn_s_barrier();
-    if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
-    }
+    if (wr == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier behind group 0 from here on
 
-    // A finished tile -> memory, accumulators back to zero.  Runs in the last MFMA segment of the item's last K-tile.
+    // A finished tile -> memory, accumulators back to zero.  Runs behind the last MFMA (and the last DMA wait) of the item's last K-tile.
     //   f32 outputs (split-K slabs, stream-K segments): 16 B per lane straight from the accumulator layout (4 consecutive columns).
     //   bf16 output (dfeat, 629 MB per call): per lane only 8 B, 16 different 128-byte lines per store instruction -- measured: the
     //   store ISSUE (line transactions), not HBM, then costs as much as the whole product.  So 32-row slices of the wave's 128 x 64
-    //   tile go through a private 4-KB LDS window (the 32 KiB the pipeline buffers leave free) and leave as whole 128-byte rows,
-    //   16 B per lane, 8 rows per store instruction.  Window image: [32 rows][128 B], 16-byte chunk ^ (row & 7), 8-byte half ^ (row >> 3 & 1):
-    //   ds_write_b64 and ds_read_b128 both conflict-free.
+    //   tile go through a private 4-KB LDS window and leave as whole 128-byte rows, 16 B per lane, 8 rows per store instruction,
+    //   written through.  Window image: [32 rows][128 B], 16-byte chunk ^ (row & 7), 8-byte half ^ (row >> 3 & 1): ds_write_b64 and
+    //   ds_read_b128 both conflict-free.
     auto epilogue = [&](const Item &it) {
         if (MODE == MODE_DFEAT) {
             int rows = a.M - it.m0;
             rows = rows > BM ? BM : rows;
             const __amdgpu_buffer_rsrc_t ro = Cursor<MODE>::make_rsrc(reinterpret_cast<bf16 *>(a.out) + (size_t)it.m0 * a.ldo + it.n0, (long long)rows * a.ldo * 2);
-            lds_byte *const win = lds + LDS_PIPE + (uint32_t)wave * 4096u;
+            lds_byte *const win = lds + LDS_WIN + (uint32_t)wave * 4096u;
             const int r16 = lane & 15, g = lane >> 4, rr = lane >> 3, c = lane & 7;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -408,160 +399,86 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
     };
 
-    Item pend = cons.it;
-    bool have_pend = false;
-    bf16x8 xf[2][4], wf[2][SCHED == 2 ? 4 : 2];
-    int buf = 0;
+    // ---- main loop: one K-tile = two phases of [fragment reads + 4 DMA requests] s_barrier [32 MFMAs] s_barrier
+    // Phase 0 reads all of W's fragments (both 32-column halves of the wave's tile stay in registers for the K-tile) and X rows 0-63;
+    // phase 1 reads X rows 64-127.  Segments = barrier intervals; group 0 loads in segments 4 t and 4 t + 2, group 1 one later.
+    //   W3:    phase 0 requests the group's X half-tile of K-tile t + 1, phase 1 waits for W of t + 1 (requested a K-tile ago) and
+    //          requests W of t + 2 into the third W buffer; behind the last MFMA: wait for X of t + 1.  Every wait is vmcnt(4):
+    //          exactly the youngest request group stays in flight.  (The probes put a request at ~100 cycles of the issuing wave's
+    //          time: eight of them in one load segment made it twice as long as the partner's 32 MFMAs -- profiles/r04_fc1_knockouts.txt.)
+    //   dfeat: phase 0 requests W and X of K-tile t + 1 (two W buffers: nothing of t + 2 has a free slot yet); its operands come from
+    //          L2, and moving X's requests to phase 1 measured equal.
+    // Hazards:  a W buffer is re-filled >= 2 segments after its last fragment read (the readers' lgkmcnt waits and a barrier lie in
+    // between); an X half-tile is re-filled by the group that read it, one barrier after that group's last read; a wave waits for its
+    // own requests (counted vmcnt) at least one barrier before any wave reads them.
+    bf16x8 xf[2][4], wf[2][4];
+    int xs = 0, ws = 0;                                   // X buffer (t & 1), W buffer (t % 3 | t & 1)
     while (cons.valid) {
-        const lds_byte *const lb = lds + (uint32_t)buf * BUF;
-        auto read_x = [&](int MH) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                xf[0][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + xb0 + (uint32_t)(4 * MH + mt) * 2048u);
-                xf[1][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + xb1 + (uint32_t)(4 * MH + mt) * 2048u);
-            }
-        };
-        auto read_w = [&](int NH) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                if (WT) {
-                    wf[0][nt] = tr_frag(lb + wt_lo[0][2 * NH + nt], lb + wt_hi[0][2 * NH + nt]);
-                    wf[1][nt] = tr_frag(lb + wt_lo[1][2 * NH + nt], lb + wt_hi[1][2 * NH + nt]);
-                } else {
-                    wf[0][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + wb0 + (uint32_t)(2 * NH + nt) * 2048u);
-                    wf[1][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + wb1 + (uint32_t)(2 * NH + nt) * 2048u);
-                }
-            }
-        };
-        auto mma = [&](int MH, int NH) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[4 * MH + mt][2 * NH + nt] = mfma(wf[ks][nt], xf[ks][mt], acc[4 * MH + mt][2 * NH + nt]);
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto seg = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if (SCHED == 2) {
-            // TWO phases of 32 MFMAs per K-tile (half the segment boundaries of the four-phase form).  Phase 0: all of W's fragments
-            // (both column halves stay in registers for the K-tile) + rows 0-63 of X, and ALL DMA requests of the next K-tile:
-            // W's two half-tiles (every wave its share) and the group's OWN X half-tile (X rows 0-127 are only ever read by waves
-            // 0-3, rows 128-255 by waves 4-7, so the group that read a half-tile last is the one that re-fills it).  Phase 1: rows
-            // 64-127 of X.  Waits: W (read by both groups at the next phase 0) in phase 1's load segment, leaving the four X requests
-            // in flight; X after the K-tile's last MFMA.  Hazards (group 0 loads in segments 4 t, 4 t + 2; group 1 one later):
-            //   W slots of K-tile t-1: last read in segments 4 t - 4 / 4 t - 3, re-filled from segment 4 t on;
-            //   X slot of group h: last read in its segment 4 t - 2 + h, re-filled by the same group in its segment 4 t + h;
-            //   W of K-tile t + 1: waited in segments 4 t + 2 / 4 t + 3, first read in 4 t + 4;  X: waited at the end of the group's
-            //   last MFMA segment, first read by the same group one barrier later.
+        const lds_byte *const lx = lds + (uint32_t)xs * LDS_X, *const lw = lds + LDS_W0 + (uint32_t)ws * LDS_W;
+        const bool fresh = !(FC1_KNOCK & 1) || cons.kt == cons.it.kt0;       // probe 1: fragments stay what the first K-tile loaded
+        // phase 0
+        if (fresh) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                if ((FC1_KNOCK & 1) && cons.kt != cons.it.kt0) break;          // probe: fragments stay what the first K-tile loaded
                 if (WT) {
-                    wf[0][nt] = tr_frag(lb + wt_lo[0][nt], lb + wt_hi[0][nt]);
-                    wf[1][nt] = tr_frag(lb + wt_lo[1][nt], lb + wt_hi[1][nt]);
+                    wf[0][nt] = tr_frag(lw + wt_lo[0][nt], lw + wt_hi[0][nt]);
+                    wf[1][nt] = tr_frag(lw + wt_lo[1][nt], lw + wt_hi[1][nt]);
                 } else {
-                    wf[0][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + wb0 + (uint32_t)nt * 2048u);
-                    wf[1][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lb + wb1 + (uint32_t)nt * 2048u);
+                    wf[0][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lw + wb0 + (uint32_t)nt * 2048u);
+                    wf[1][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lw + wb1 + (uint32_t)nt * 2048u);
                 }
             }
-            if (!(FC1_KNOCK & 1) || cons.kt == cons.it.kt0) read_x(0);
-            if (prod.valid && !(FC1_KNOCK & 2)) {
-                stage(prod, 2, buf ^ 1);
-                stage(prod, 3, buf ^ 1);
-                stage_x_own(prod, buf ^ 1);
-            }
-            seg();
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma(wf[ks][nt], xf[ks][mt], acc[mt][nt]);
-            __builtin_amdgcn_s_setprio(0);
-            seg();
-            if (!(FC1_KNOCK & 1) || cons.kt == cons.it.kt0) read_x(1);
-            if (prod.valid && !(FC1_KNOCK & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            seg();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[4 + mt][nt] = mfma(wf[ks][nt], xf[ks][mt], acc[4 + mt][nt]);
-            __builtin_amdgcn_s_setprio(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            prod.advance(a);
-            if (cons.kt + 1 == cons.it.kt1) epilogue(cons.it);
-            cons.advance(a);
-            seg();
-            buf ^= 1;
-            continue;
-        }
-
-        // phase 0: quadrant (rows 0-63, columns 0-31); request X1 of the next K-tile
-        read_w(0);
-        read_x(0);
-        if (prod.valid) stage(prod, 1, buf ^ 1);
-        if (have_pend) {
-            epilogue(pend);
-            have_pend = false;
-        }
-        seg();
-        mma(0, 0);
-        seg();
-        // phase 1: (rows 0-63, columns 32-63); request W0
-        read_w(1);
-        if (prod.valid) stage(prod, 2, buf ^ 1);
-        seg();
-        mma(0, 1);
-        seg();
-        // phase 2: (rows 64-127, columns 32-63); request W1
-        read_x(1);
-        if (prod.valid) stage(prod, 3, buf ^ 1);
-        seg();
-        mma(1, 1);
-        seg();
-        // phase 3: (rows 64-127, columns 0-31); request X0 of the K-tile after next into THIS buffer (its X0 was last read in phase 2),
-        // then wait for everything but those two requests: the next K-tile is complete
-        read_w(0);
-        if (prodx.valid) {
-            stage(prodx, 0, buf);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        seg();
-        mma(1, 0);
-
-        prod.advance(a);
-        prodx.advance(a);
-        // consumer: at the end of an item its tile is complete.  (Spreading the four quadrants' stores over the load segments of
-        // the next K-tile was measured SLOWER, 0.46 vs 0.42 ms for dfeat: vmcnt retires in order, so stores issued ahead of the
-        // K-tile's one DMA wait hold that wait up; behind it they have a whole K-tile to drain.)
-        if (cons.kt + 1 == cons.it.kt1) {
-            if (MODE == MODE_DFEAT && wr == 0) {   // group 0's epilogue moves into its NEXT load segment: beside group 1's, not before it
-                pend = cons.it;
-                have_pend = true;
-            } else {
-                epilogue(cons.it);
+            for (int mt = 0; mt < 4; ++mt) {
+                xf[0][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lx + xb0 + (uint32_t)mt * 2048u);
+                xf[1][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lx + xb1 + (uint32_t)mt * 2048u);
             }
         }
+        if (!(FC1_KNOCK & 2)) {
+            if (!W3 && pw.valid) req_w(pw, ws ^ 1);
+            if (px.valid) req_x(px, xs ^ 1);
+        }
+        seg();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma(wf[ks][nt], xf[ks][mt], acc[mt][nt]);
+        __builtin_amdgcn_s_setprio(0);
+        seg();
+        // phase 1
+        if (fresh) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                xf[0][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lx + xb0 + (uint32_t)(4 + mt) * 2048u);
+                xf[1][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lx + xb1 + (uint32_t)(4 + mt) * 2048u);
+            }
+        }
+        if (px.valid && !(FC1_KNOCK & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // W of K-tile t + 1 (its X may still fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (W3 && pw.valid && !(FC1_KNOCK & 2)) req_w(pw, ws == 0 ? 2 : ws - 1);                  // (t + 2) % 3 == (t - 1) % 3
+        seg();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[4 + mt][nt] = mfma(wf[ks][nt], xf[ks][mt], acc[4 + mt][nt]);
+        __builtin_amdgcn_s_setprio(0);
+        if (W3 && pw.valid && !(FC1_KNOCK & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // X of K-tile t + 1 (W of t + 2 may still fly)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        px.advance(a);
+        pw.advance(a);
+        if (cons.kt + 1 == cons.it.kt1) epilogue(cons.it);
         cons.advance(a);
         seg();
-        buf ^= 1;
+        xs ^= 1;
+        ws = W3 ? (ws == 2 ? 0 : ws + 1) : ws ^ 1;
     }
-    if (have_pend) epilogue(pend);
-    if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+    if (wr == 0) __builtin_amdgcn_s_barrier();
 #else
     (void)a;
 #endif
@@ -629,14 +546,11 @@ static int fc1_launch(const fc1::Args &a, int grid, hipStream_t st, const char *
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
         if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "%s: hipFuncSetAttribute(%d B of LDS): %s", what, fc1::LDS_BYTES, hipGetErrorString(e));
         attr_done[dev] = true;
     }
-    const char *sch = getenv("INV_FC1_SCHED");                                  // EXPERIMENT: 4 = the four-phase schedule
-    if (sch && sch[0] == '4') hipLaunchKernelGGL((fc1::k_fc1_gemm<MODE, 4>), dim3(grid), dim3(fc1::THREADS), fc1::LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((fc1::k_fc1_gemm<MODE, 2>), dim3(grid), dim3(fc1::THREADS), fc1::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((fc1::k_fc1_gemm<MODE>), dim3(grid), dim3(fc1::THREADS), fc1::LDS_BYTES, st, a);
     return fc1_status(what);
 }
 

@@ -12,6 +12,6 @@ out = os.path.join(ROOT, "tools", "exp", f"lib_{name}.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 only = os.environ.get("ONLY_SOURCES")                      # e.g. "inv_api.hip": a step-kernel variant needs nothing else
 srcs = [s for s in B.SOURCES if not only or os.path.basename(s) in only.split(",")]
-cmd = [B.hipcc()] + B.FLAGS + defs + ["-I", os.path.join(ROOT, "include"), "-o", out] + srcs
+cmd = [B.hipcc()] + B.FLAGS + ["-DINV_TOOLS_BUILD"] + defs + ["-I", os.path.join(ROOT, "include"), "-o", out] + srcs
 subprocess.check_call(cmd)
 print(out)

@@ -56,26 +56,17 @@ def main():
         for _ in range(3):
             fn()
     torch.cuda.synchronize()
-    res = {k: {"ours_ms": [], "library_ms": [], "ours_sched4_ms": []} for k in ours}
-    import os
-    ab = os.environ.get("FC1_SCHED_AB") == "1"           # experiment: the four-phase schedule beside the shipped one
+    res = {k: {"ours_ms": [], "library_ms": []} for k in ours}
     for _ in range(rounds):
         for k in ours:
             res[k]["ours_ms"].append(round(time(ours[k]), 4))
             res[k]["library_ms"].append(round(time(theirs[k]), 4))
-            if ab:
-                os.environ["INV_FC1_SCHED"] = "4"
-                res[k]["ours_sched4_ms"].append(round(time(ours[k]), 4))
-                del os.environ["INV_FC1_SCHED"]
     flop = 2.0 * B * NH * K
     out = {"B": B, "slabs": slabs, "gpu": torch.cuda.get_device_name(0)}
     for k, v in res.items():
         a, b = sorted(v["ours_ms"]), sorted(v["library_ms"])
         out[k] = {"ours_ms_median": a[len(a) // 2], "ours_ms_min": a[0], "library_ms_median": b[len(b) // 2], "library_ms_min": b[0],
                   "ours_pflops": round(flop / (a[len(a) // 2] * 1e-3) / 1e15, 3), "library_pflops": round(flop / (b[len(b) // 2] * 1e-3) / 1e15, 3)}
-        if v["ours_sched4_ms"]:
-            c = sorted(v["ours_sched4_ms"])
-            out[k]["ours_four_phase_ms_median"] = c[len(c) // 2]
     # numerics on the random data (f32 accumulation both ways)
     ours["fwd"]()
     ref = feat[:1024].float() @ wf.float().t()
