@@ -14,9 +14,14 @@ generated before the timed region), device dummy opponent, core tick, reward/don
 Inputs (env state) are resident in HBM before the timed region.  Envs are sharded over ranks
 by global index with no data-path collective (weak scaling: 16 384 envs per GPU).
 
-Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (k_step) from HIP events on
+The timed loop of `value` writes every step's outputs into one of 32 DISTINCT buffers (3.8 GB of observations: what a collector
+that keeps a rollout does, and a footprint the 256 MiB Infinity Cache cannot hold), so `roofline.achieved / frac` are HBM figures.
+The same launches re-writing ONE 118 MB buffer (rounds 1-3's headline loop; memory-side-cache writes) are timed beside it and
+reported as `value_cache_resident` / `roofline.*_cache_resident`.
+
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (k_step4) from HIP events on
 the launch stream; `cpu_baseline` times the CPU oracle (test infrastructure, used here only as
-the yardstick) on a bounded sample of the same workload.
+the yardstick) on a bounded sample of the same workload, in a child process of its own (OpenMP binding set before the runtime starts).
 """
 import argparse
 import json
@@ -109,6 +114,21 @@ def thread_placement():
     return out
 
 
+def cpu_baseline_child(difficulty):
+    """cpu_baseline() in a fresh process whose OpenMP runtime starts with OMP_PROC_BIND=close / OMP_PLACES=cores (the variables are
+    read once, when the runtime initialises -- too late in a process that has imported torch)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("OMP_PROC_BIND", "close")
+    env.setdefault("OMP_PLACES", "cores")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--difficulty", difficulty],
+                       env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"error": f"cpu baseline child failed (rc {r.returncode}): {r.stderr[-300:]}"}
+    return json.loads(line[-1])
+
+
 def cpu_baseline(difficulty, budget_s=8.0):
     """The C oracle (bit-checked against the reference) on the host cores: same seeds, same action stream, same
     config; bounded sample.  Threads = what the job may use (affinity / cgroup quota, both reported), the output
@@ -166,6 +186,7 @@ def cpu_baseline(difficulty, budget_s=8.0):
         scaling["16"] = round(run(NUM_ENVS, 16, 3.0)[0])
     v4, _ = run(4, 1, 1.0)
     vpy = python_loop(4, 1.0)
+    vpy_big = python_loop(NUM_ENVS, 0.0)                  # ONE vector step of 16 384 env objects (N = 4 and N = 16 384)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -181,6 +202,13 @@ def cpu_baseline(difficulty, budget_s=8.0):
             "speedup_all_threads_vs_one_on_its_slice": round(v / v1s, 2),
             "n4_one_core_env_steps_per_s": round(v4),
             "n4_python_object_loop_env_steps_per_s": round(vpy),
+            "n16384_python_object_loop_env_steps_per_s": round(vpy_big),
+            "python_object_loop": "the reference's MultiEnvRunner structure (env_wrappers.py:494-528) over the C port: a Python loop over env "
+                                  "objects, one C call per env for dummy / step / observation, np.stack; one thread; N = 16 384: one vector step",
+            # the Python reference itself cannot travel to the GPU box: its rates measured in the survey container
+            "reference_python_container": {"n4_env_steps_per_s": 11300, "n16384_env_steps_per_s": 8100, "eight_processes_x_2048_envs_env_steps_per_s": 89400,
+                                           "what": "MultiEnvRunner.step + training-loop-style reset, vs_dummy easy, no policy (inversus_rl/env_wrappers.py:485-528)",
+                                           "host": "8 vCPU Intel Xeon @ 2.10 GHz (the survey container), NOT this box"},
             "host": {"cpu_model": model, "nproc": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota": quota,
                      "placement": thread_placement()}}
 
@@ -593,9 +621,10 @@ def main():
     ap.add_argument("--difficulty", default="easy", choices=["easy", "hard"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
-    ap.add_argument("--no-streaming", action="store_true",
-                    help="skip the second timed loop (the same launches into 32 distinct buffers); for profiling the headline loop alone, "
-                         "so that a rocprofv3 average of k_step4 is the cache-resident launches only")
+    ap.add_argument("--no-cache-resident", action="store_true",
+                    help="skip the second timed loop (the same launches re-writing ONE output buffer); for profiling the headline loop alone, "
+                         "so that a rocprofv3 average of k_step4 is the streaming launches only")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit; no GPU is touched")
     ap.add_argument("--no-c4", action="store_true",
                     help="N > 1 only: skip the self-play PPO iteration (collector + fused update + gradient all-reduce) extra")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -606,6 +635,9 @@ def main():
                     help="initialise the process group even for one rank (runs the RCCL code path on a 1-GPU box)")
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.difficulty)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:                 # no launcher: be the launcher (before any GPU call)
         raise SystemExit(spawn_ranks(args.gpus))
 
@@ -643,18 +675,14 @@ def main():
     b = DeviceEnvBatch(n, W, H, K, opponent="dummy", difficulty=args.difficulty, opp_seed=1, env_offset=off)
     b.seed(off + np.arange(n, dtype=np.int64))       # seed = base 0 + global env index
     b.reset()
-    out = b._alloc_out((), True, False, False, None)  # fixed output buffers: no allocator in the loop
     # the synthetic P1 action stream of every step is generated BEFORE the timed region (inputs resident in HBM);
     # every repeat replays the same K action rows on the env state the previous region left behind
     total = args.warmup + args.steps
     a1_all = torch.empty((total, n), dtype=torch.uint8, device="cuda")
     for t in range(total):
         b.uniform_actions(1234, t, out=a1_all[t])
-    step = b.make_stepper(out, None, auto_reset=True)   # one pre-marshalled ctypes call per vector step
     base = a1_all.data_ptr()
-
-    for t in range(args.warmup):
-        step(base + t * n)
+    from inversus_reinforcement_learning_amd.device_env import StepResult
 
     def fence():
         torch.cuda.synchronize()
@@ -678,59 +706,69 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         return [float(t) for t in v.tolist()]
 
+    # N > 1: every rank's GPU, gathered -- the line proves by itself that N ranks sat on N distinct devices
+    me = gpu_identity(torch)
+    me["rank"], me["local_rank"], me["device_index"] = rank, local_rank, dev
+    if use_dist:
+        gpus = [None] * world
+        dist.all_gather_object(gpus, me)
+        ranks_seen = dist.get_world_size()
+        ids = [g.get("uuid") or f"no-uuid-{g.get('rank')}" for g in gpus]
+        if len(set(ids)) != len(ids) and not args.share_device:
+            raise SystemExit(f"rank {rank}: {world} ranks but the GPUs are not distinct: {ids} (--share-device rehearses ranks on one GPU)")
+    else:
+        gpus, ranks_seen = [me], 1
+
     # HIP events on the launch stream around groups of EV_GROUP consecutive k_step launches (an event
     # pair per launch costs ~2 us of queue markers per step); kernel_ms = group time / launches, so it
     # includes the ~1.5 us dependent-launch boundary between steps of one env batch.
     groups = [(k, min(k + EV_GROUP, args.steps)) for k in range(0, args.steps, EV_GROUP)]
-    regions = []                                     # (wall seconds max over ranks, kernel ms of this rank) per repeat
-    for _ in range(max(1, args.repeats)):
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
-        fence()
-        t0 = time.perf_counter()
-        for (lo, hi), (e0, e1) in zip(groups, ev):
-            e0.record()
-            for k in range(lo, hi):
-                step(base + (args.warmup + k) * n)
-            e1.record()
-        fence()
-        dt = time.perf_counter() - t0
-        regions.append((over_ranks(dt, dist.ReduceOp.MAX), sum(s.elapsed_time(e) for s, e in ev) / args.steps))
-    b.check()
 
-    # The same launches in the STREAMING regime: the loop above re-writes ONE 118 MB observation buffer, which the 256 MiB Infinity
-    # Cache keeps resident; a collector that keeps every step's observations writes distinct buffers.  Same kernel, same actions,
-    # same protocol (repeats x steps launches, HIP events per group, median region), output slot = step % STREAM_SLOTS (3.8 GB).
-    STREAM_SLOTS = 1 if args.no_streaming else 32           # --no-streaming: the loop below degenerates to a short re-run of the headline loop
-    from inversus_reinforcement_learning_amd.device_env import StepResult
-    so = b._alloc_out((STREAM_SLOTS,), True, False, False, None)
-    slots = [StepResult(**{k2: (getattr(so, k2)[j] if getattr(so, k2) is not None else None) for k2 in StepResult.__slots__})
-             for j in range(STREAM_SLOTS)]
-    sstep = [b.make_stepper(slots[j], None, auto_reset=True) for j in range(STREAM_SLOTS)]
-    for t in range(max(args.warmup, STREAM_SLOTS)):
-        sstep[t % STREAM_SLOTS](base + (t % total) * n)
-    sregions = []
-    for _ in range(1 if args.no_streaming else max(1, args.repeats)):
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
-        fence()
-        t0 = time.perf_counter()
-        for (lo, hi), (e0, e1) in zip(groups, ev):
-            e0.record()
-            for k in range(lo, hi):
-                sstep[k % STREAM_SLOTS](base + (args.warmup + k) * n)
-            e1.record()
-        fence()
-        sdt = time.perf_counter() - t0
-        sregions.append((over_ranks(sdt, dist.ReduceOp.MAX), sum(s_.elapsed_time(e_) for s_, e_ in ev) / args.steps))
-    b.check()
-    sorder = sorted(range(len(sregions)), key=lambda i: sregions[i][0])
-    sdt, skern_ms = sregions[sorder[len(sorder) // 2]]
-    skern_ms_ranks = gather(skern_ms)
-    del so, slots, sstep
+    def timed_loop(slots_n, repeats):
+        """`repeats` regions of exactly args.steps vector steps into `slots_n` output buffers (slot = step % slots_n; no allocator in
+        the loop).  -> [(wall seconds, max over ranks; kernel ms per step of this rank)]"""
+        so = b._alloc_out((slots_n,), True, False, False, None)
+        slots = [StepResult(**{k2: (getattr(so, k2)[j] if getattr(so, k2) is not None else None) for k2 in StepResult.__slots__})
+                 for j in range(slots_n)]
+        stp = [b.make_stepper(slots[j], None, auto_reset=True) for j in range(slots_n)]      # one pre-marshalled ctypes call per vector step
+        for t in range(max(args.warmup, slots_n)):
+            stp[t % slots_n](base + (t % total) * n)
+        regs = []
+        for _ in range(max(1, repeats)):
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
+            fence()
+            t0 = time.perf_counter()
+            for (lo, hi), (e0, e1) in zip(groups, ev):
+                e0.record()
+                for k in range(lo, hi):
+                    stp[k % slots_n](base + (args.warmup + k) * n)
+                e1.record()
+            fence()
+            dt_ = time.perf_counter() - t0
+            regs.append((over_ranks(dt_, dist.ReduceOp.MAX), sum(s_.elapsed_time(e_) for s_, e_ in ev) / args.steps))
+        b.check()
+        del so, slots, stp
+        return regs
+
+    def median_region(regs):
+        order = sorted(range(len(regs)), key=lambda i: regs[i][0])
+        return regs[order[len(order) // 2]]          # the median region by wall time (max over ranks)
+
+    # The headline loop: 32 distinct output buffers (3.8 GB of observations: every byte goes to HBM) ...
+    STREAM_SLOTS = 32
+    regions = timed_loop(STREAM_SLOTS, args.repeats)
+    dt, kern_ms = median_region(regions)
+    kern_ms_ranks = gather(kern_ms)                  # the same region's k_step time on every rank: a slow rank is visible
+    # ... and the same launches, same actions, same protocol re-writing ONE 118 MB buffer, which the 256 MiB Infinity Cache keeps resident
+    # (rounds 1-3's headline loop): memory-side-cache writes, not HBM
+    cregions = None if args.no_cache_resident else timed_loop(1, args.repeats)
+    if cregions is not None:
+        cdt, ckern_ms = median_region(cregions)
+        ckern_ms_ranks = gather(ckern_ms)
 
     # N > 1 (or a forced one-rank group): C4's self-play PPO iteration with the gradient all-reduce, on every rank
     c4 = None
     if use_dist and not args.no_c4:
-        del sregions
         torch.cuda.empty_cache()
         try:
             c4 = c4_iteration(torch, np, dist, n, rank, world, off, args.backend)
@@ -740,17 +778,10 @@ def main():
                 raise
         torch.cuda.empty_cache()
 
-    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
-    med = order[len(order) // 2]                     # the median region by wall time (max over ranks)
-    dt, kern_ms = regions[med]
-    kern_ms_ranks = gather(kern_ms)                  # the same region's k_step time on every rank: a slow rank is visible
-
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_env_step() * n
         kern_ms_roof = sorted(kern_ms_ranks)[len(kern_ms_ranks) // 2]
         achieved = bytes_per_launch / (kern_ms_roof * 1e-3) / 1e9
-        skern_ms_roof = sorted(skern_ms_ranks)[len(skern_ms_ranks) // 2]
-        achieved_streaming = bytes_per_launch / (skern_ms_roof * 1e-3) / 1e9
         res = {
             "metric": "env-steps/sec at 16384 envs per MI355X",
             "value": world * n * args.steps / dt,
@@ -765,31 +796,38 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"vs_dummy_{args.difficulty}: {n} envs/GPU, 15x10 grid, K=16, step+obs kernels only "
-                                   "(Philox a1 stream, device dummy a2, reward/done, auto-reset, 12-ch obs)",
+                                   "(Philox a1 stream, device dummy a2, reward/done, auto-reset, 12-ch obs), every step's outputs kept "
+                                   f"({STREAM_SLOTS} distinct output buffers = 3.8 GB of observations: HBM writes)",
                        "envs_per_gpu": n, "sharding": f"env-shards x{world}, no data-path collective",
-                       "backend": (args.backend if use_dist else "none"), "gpu": gpu_identity(torch)},
+                       "backend": (args.backend if use_dist else "none"), "gpu": gpus[0], "gpus": gpus, "ranks_seen": ranks_seen,
+                       "distinct_gpus": len({g.get("uuid") or f"no-uuid-{g.get('rank')}" for g in gpus})},
             "repeats": len(regions), "protocol": "median of the repeats' wall time (each = exactly `steps` vector steps, barrier + synchronize on both sides)",
             "ms_per_step_repeats": [round(r[0] / args.steps * 1e3, 6) for r in regions],
-            # `frac` / `achieved` / `kernel_ms` describe the timed loop of `value`: ONE output buffer re-written every step, which the
-            # Infinity Cache absorbs (regime "cache-resident"); the *_streaming fields are the same launches into 32 distinct buffers
-            # (3.8 GB: every byte goes to HBM) -- that one is the HBM fraction.
+            # `value`, `achieved`, `frac`, `kernel_ms` all describe ONE loop: the launches that write 32 distinct buffers, i.e. HBM traffic.
+            # The *_cache_resident fields are the same launches re-writing one 118 MB buffer (the Infinity Cache absorbs it): rounds 1-3
+            # reported THAT loop as `value` / `frac` (0.81 of "8 TB/s" -- a memory-side-cache number, not an HBM one).
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(args.difficulty),
-                         "regime": "cache-resident (one 118 MB output buffer re-written per step: memory-side-cache writes); "
-                                   "*_streaming = the same launches into 32 distinct buffers (HBM writes)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(args.difficulty, "_streaming"),
+                         "regime": "streaming: every launch writes its 118 MB of observations to a buffer of its own (32 slots, 3.8 GB)",
                          "kernel": "k_step4 (four envs per wavefront; csrc/inv_step4.h)" if b.step_kernel != "wave" else "k_step",
                          "kernel_ms": kern_ms_roof, "kernel_ms_per_rank": [round(x, 6) for x in kern_ms_ranks],
-                         "achieved_streaming": None if args.no_streaming else achieved_streaming,
-                         "frac_streaming": None if args.no_streaming else achieved_streaming / HBM_PEAK_GBS,
-                         "kernel_ms_streaming": skern_ms_roof, "kernel_ms_streaming_per_rank": [round(x, 6) for x in skern_ms_ranks],
-                         "value_streaming": world * n * args.steps / sdt, "ms_per_step_streaming": sdt / args.steps * 1e3,
-                         "traffic_streaming": traffic_from_profiles(args.difficulty, "_streaming"),
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step()},
         }
+        if cregions is not None:
+            ckern_ms_roof = sorted(ckern_ms_ranks)[len(ckern_ms_ranks) // 2]
+            cach = bytes_per_launch / (ckern_ms_roof * 1e-3) / 1e9
+            res["value_cache_resident"] = world * n * args.steps / cdt
+            res["ms_per_step_cache_resident"] = cdt / args.steps * 1e3
+            res["roofline"].update({
+                "achieved_cache_resident": cach, "frac_cache_resident": cach / HBM_PEAK_GBS,
+                "kernel_ms_cache_resident": ckern_ms_roof, "kernel_ms_cache_resident_per_rank": [round(x, 6) for x in ckern_ms_ranks],
+                "traffic_cache_resident": traffic_from_profiles(args.difficulty),
+                "regime_cache_resident": "one 118 MB output buffer re-written per step: memory-side-cache (Infinity Cache) writes -- its "
+                                         "'fraction of 8 TB/s' is NOT an HBM fraction"})
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would sit in the barrier)
-            res["cpu_baseline"] = cpu_baseline(args.difficulty)
+            res["cpu_baseline"] = cpu_baseline_child(args.difficulty)
         if not args.no_extras and world == 1:
-            del b, out, a1_all, step
+            del b, a1_all
             torch.cuda.empty_cache()
             res["extras"] = side_measurements(torch, np, n)
             two = res["extras"].get("two independent env shards of 8192 on two HIP streams (vs_dummy_easy 15x10 f32, wall clock per full 16384-env step)")

@@ -9,16 +9,11 @@
 //
 // One kernel core for all three: a 256 x 256 output tile per 512-thread workgroup (8 waves = 2 x 4, a wave owns 128 x 64 = 8 x 4 MFMA
 // tiles = 128 accumulator registers), K-tiles of 64 streamed HBM / L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no
-// VGPR round trip) into two 64-KB buffers of four 16-KB half-tiles (X rows 0-127 / 128-255, W rows 0-127 / 128-255).  A K-tile is
-// four PHASES (one quadrant of the wave's tile each: 16 MFMAs); a phase = [LDS fragment reads + one half-tile's DMA requests]
-// s_barrier [16 MFMAs] s_barrier, and waves 4-7 run ONE BARRIER BEHIND waves 0-3, so on every SIMD one wave computes while its
-// partner loads (the two waves of a SIMD are w and w + 4).  DMA requests stay in flight across the barriers: the only vmcnt wait
-// of a K-tile sits in its last phase and leaves the newest half-tile outstanding.  Hazards (segments = barrier intervals; group 0
-// loads in even segments, group 1 in odd ones):
-//   write-after-read   a half-tile slot is re-filled no earlier than two segments after the last ds_read of its old content
-//                      (the reader's lgkmcnt wait and the next barrier lie in between);
-//   read-after-write   every wave waits for its own requests (counted vmcnt) in the phase BEFORE the first read, and a barrier
-//                      separates that wait from every reader.
+// VGPR round trip) in 16-KB half-tiles (X rows 0-127 / 128-255, W rows 0-127 / 128-255; two X buffers, three W buffers -- two plus
+// an epilogue window for dfeat -- = all 160 KiB of the CU).  A K-tile is two PHASES of [LDS fragment reads + four DMA requests]
+// s_barrier [32 MFMAs] s_barrier, and waves 4-7 run ONE BARRIER BEHIND waves 0-3, so on every SIMD one wave computes while its
+// partner loads (the two waves of a SIMD are w and w + 4).  DMA requests stay in flight across the barriers (raw s_barrier, counted
+// vmcnt: every wait leaves exactly the youngest group of four requests outstanding).  The hazard table sits at the main loop.
 // LDS image of a half-tile [128 rows][64 k]: 1-KB pieces of 8 rows x 128 B (one DMA wave-instruction = one piece = 8 full
 // 128-byte lines of the operand), the 16-byte chunk index XORed with (row >> 1) & 7 on the SOURCE address (the DMA writes LDS
 // lane-linearly) and on the fragment reads: every ds_read_b128 quarter-wave touches 16 different bank groups.
@@ -37,9 +32,8 @@
 //            side on one XCD.  f32 segment slabs, summed and transposed into the module's [j][c P + p] order by k_fc1_dw_reduce.
 // For a fixed split the result for a sample does not depend on the batch or on its position in it (fixed K order per output
 // element, no atomics: bit-identical between launches).  Measured, same-process A/B against the GEMM library on random data
-// (B = 16 384, tools/fc1_bench.py, profiles/r04_fc1_experiments.md): forward 0.27 vs 0.31 ms, dfeat 0.34 vs 0.37, dw 0.37 + 0.03
-// (reduce into the module layout) vs 0.36 + 0.04 (unpack) -- 1.2 / 0.95 / 0.87 PFLOP/s; what holds them there is written down next
-// to the numbers.
+// (B = 16 384, tools/fc1_bench.py, profiles/r04_fc1_experiments.md): forward 0.25 vs 0.31 ms (1.29 PFLOP/s), dfeat 0.31-0.34 vs 0.37,
+// dw + its reduce into the module layout 0.33 vs 0.36 + 0.04 (unpack); what holds them there is written down next to the numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

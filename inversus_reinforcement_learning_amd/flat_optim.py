@@ -116,6 +116,7 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.workspace = torch.zeros(int(self.lib.inv_clip_adam_workspace_bytes()), dtype=torch.uint8, device=dev)
         self.steps = 0
+        self.lr_source = None                                           # FlatAdamHandle's param group, once a handle exists
 
     def zero_grad(self):
         self.grad.zero_()
@@ -133,6 +134,8 @@ class FlatAdam:
         """One optimizer step from the gradients in the flat bucket.  -> 0-dim f32 tensor: the pre-clip global gradient norm."""
         self._check_aliases()
         self.steps += 1
+        if self.lr_source is not None:
+            self.lr = float(self.lr_source["lr"])
         with torch.cuda.device(self.flat.device):
             rc = self.lib.inv_clip_adam_step(_ptr(self.flat), _ptr(self.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), self.n, self.lr,
                                              float(self.betas[0]), float(self.betas[1]), self.eps, self.steps, self.max_grad_norm,
@@ -149,39 +152,51 @@ class FlatAdamHandle:
     accidental second optimizer stepping the same parameters would be a silent bug."""
 
     class _Group(dict):
-        def __init__(self, adam):
-            super().__init__(params=adam.params, betas=adam.betas, eps=adam.eps, weight_decay=0.0)
-            self._adam = adam
+        """A real dict: "lr" is an ordinary key (so `in`, keys(), items(), dict(group), copy(), setdefault see it), and every write of
+        it is pushed into FlatAdam, which reads its learning rate back from here at each step -- the dict is the single source."""
 
-        def __getitem__(self, k):
-            return self._adam.lr if k == "lr" else super().__getitem__(k)
+        def __init__(self, adam):
+            super().__init__(params=adam.params, lr=adam.lr, betas=adam.betas, eps=adam.eps, weight_decay=0.0)
+            self._adam = adam
 
         def __setitem__(self, k, v):
             if k == "lr":
-                self._adam.lr = float(v)
-            else:
-                super().__setitem__(k, v)
+                v = float(v)
+                self._adam.lr = v
+            super().__setitem__(k, v)
 
-        def get(self, k, default=None):
-            return self._adam.lr if k == "lr" else super().get(k, default)
+        def update(self, *a, **kw):
+            for k, v in dict(*a, **kw).items():
+                self[k] = v
+
+        def setdefault(self, k, default=None):
+            if k not in self:
+                self[k] = default
+            return self[k]
 
     def __init__(self, adam):
         self.adam = adam
         self.param_groups = [self._Group(adam)]
+        adam.lr_source = self.param_groups[0]                           # FlatAdam.step() takes param_groups[0]["lr"]
 
     def zero_grad(self, set_to_none=False):
         self.adam.zero_grad()                                            # never to None: the gradients alias the flat bucket
 
     def state_dict(self):
         a = self.adam
-        return {"kind": "FlatAdam", "lr": a.lr, "betas": tuple(a.betas), "eps": a.eps, "max_grad_norm": a.max_grad_norm,
-                "steps": a.steps, "exp_avg": a.exp_avg.detach().clone(), "exp_avg_sq": a.exp_avg_sq.detach().clone()}
+        return {"kind": "FlatAdam", "lr": float(self.param_groups[0]["lr"]), "betas": tuple(a.betas), "eps": a.eps, "max_grad_norm": a.max_grad_norm,
+                "steps": a.steps, "exp_avg": a.exp_avg.detach().clone(), "exp_avg_sq": a.exp_avg_sq.detach().clone(),
+                "param_shapes": [tuple(p.shape) for p in a.params]}       # the flat buffers mean nothing without the order they were cut in
 
     def load_state_dict(self, sd):
         a = self.adam
         if sd.get("kind") != "FlatAdam" or sd["exp_avg"].numel() != a.n:
             raise ValueError("not a FlatAdam state of this parameter set")
-        a.lr, a.betas, a.eps, a.max_grad_norm = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"]), float(sd["max_grad_norm"])
+        shapes = sd.get("param_shapes")
+        if shapes is not None and [tuple(x) for x in shapes] != [tuple(p.shape) for p in a.params]:
+            raise ValueError("FlatAdam state was saved for parameters of other shapes / another order: the flat moments would land on the wrong weights")
+        self.param_groups[0]["lr"] = float(sd["lr"])
+        a.betas, a.eps, a.max_grad_norm = tuple(sd["betas"]), float(sd["eps"]), float(sd["max_grad_norm"])
         a.steps = int(sd["steps"])
         a.exp_avg.copy_(sd["exp_avg"].to(a.exp_avg.device))
         a.exp_avg_sq.copy_(sd["exp_avg_sq"].to(a.exp_avg_sq.device))

@@ -174,8 +174,10 @@ class PPOAgent:
         (`stats["minibatches"]`, f64 arrays) and the normalised advantages (`stats["advantages"]`)."""
         if len(self.obs_grid_buffer) == 0:
             return {}
+        from . import roctx
         if advantages is None:
-            advantages, returns = self._advantages_device()
+            with roctx.range("ppo.gae"):
+                advantages, returns = self._advantages_device()
         else:
             advantages, returns = self._t(advantages, torch.float32).reshape(-1), self._t(returns, torch.float32).reshape(-1)
         mean, std = parallel.global_mean_std(advantages)                  # population std, all ranks (:173)
@@ -206,6 +208,7 @@ class PPOAgent:
             for start in range(0, num_samples, self.batch_size):
                 idx = indices[start:start + self.batch_size]
                 if self.direct_grads:
+                    roctx.push("ppo.minibatch (fused forward + backward + clip/Adam)")
                     # fused trunk / heads / loss kernels forward and backward without the autograd engine; every gradient is
                     # written into the flat bucket (nothing to zero), the heads' all-reduce starts before the trunk's backward
                     means = self.train_fwd.loss_and_grads(obs_grid[idx], obs_extra[idx], actions[idx], old_log_probs[idx], advantages[idx],
@@ -223,6 +226,7 @@ class PPOAgent:
                     tot_v += value_loss
                     tot_e += entropy
                     num_updates += 1
+                    roctx.pop()
                     continue
                 if self.train_fwd is not None:                            # fused trunk kernels; reads packed observations as is
                     logits, values = self.train_fwd(obs_grid[idx], obs_extra[idx])

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from . import parallel
+from . import parallel, roctx
 from .device_env import DeviceEnvBatch, unpack_obs
 from .policies import InversusCNNPolicy
 from .ppo_agent import PPOAgent
@@ -94,6 +94,10 @@ class RolloutCollector:
         return torch.distributions.Categorical(logits=logits, validate_args=False).sample().to(torch.uint8)
 
     def collect(self, steps):
+        with roctx.range("rollout.collect"):
+            return self._collect(steps)
+
+    def _collect(self, steps):
         b, agent = self.batch, self.agent
         for _ in range(steps):
             grid, extra = self.obs
@@ -202,9 +206,10 @@ def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, w
     stats, t0 = {}, time.time()
     while step_count < total_steps:
         todo = min(steps_per_env, -(-(total_steps - step_count) // num_envs))
-        collector.collect(todo)
+        collector.collect(todo)                                         # (a roctx range of its own: "rollout.collect")
         step_count += todo * num_envs
-        stats = agent.update()
+        with roctx.range("ppo.update"):
+            stats = agent.update()
         updates += 1
         if world_size > 1 and updates % DIGEST_EVERY == 0:
             parallel.assert_replicas_in_sync(policy)

@@ -27,13 +27,28 @@ def parse_line(proc):
 
 
 def check_streaming_fields(res):
-    """Round 3: the parsed line carries the HBM-streaming regime (32 distinct output buffers) beside the cache-resident loop."""
+    """Round 4: `value` / `roofline.frac` describe the HBM-streaming loop (32 distinct output buffers); the loop that re-writes ONE buffer
+    (the Infinity Cache absorbs it: rounds 1-3's headline) rides beside it as *_cache_resident."""
     r = res["roofline"]
-    assert "cache-resident" in r["regime"]
-    assert r["kernel_ms_streaming"] > 0 and len(r["kernel_ms_streaming_per_rank"]) == res["n_gpus"]
-    assert r["achieved_streaming"] == pytest.approx(7369 * 16384 / (r["kernel_ms_streaming"] * 1e-3) / 1e9, rel=1e-6)
-    assert r["frac_streaming"] == pytest.approx(r["achieved_streaming"] / r["peak"], rel=1e-9)
-    assert r["value_streaming"] == pytest.approx(res["n_gpus"] * 16384 / (r["ms_per_step_streaming"] * 1e-3), rel=1e-6)
+    assert r["bound"] == "hbm" and r["regime"].startswith("streaming")
+    assert r["kernel_ms"] > 0 and len(r["kernel_ms_per_rank"]) == res["n_gpus"]
+    assert r["achieved"] == pytest.approx(7369 * 16384 / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    assert r["kernel_ms_cache_resident"] > 0 and len(r["kernel_ms_cache_resident_per_rank"]) == res["n_gpus"]
+    assert r["frac_cache_resident"] == pytest.approx(7369 * 16384 / (r["kernel_ms_cache_resident"] * 1e-3) / 1e9 / r["peak"], rel=1e-6)
+    assert res["value_cache_resident"] == pytest.approx(res["n_gpus"] * 16384 / (res["ms_per_step_cache_resident"] * 1e-3), rel=1e-6)
+    assert "32 distinct output buffers" in res["config"]["workload"]
+
+
+def check_gpu_identities(res, world, shared):
+    """Round 4: the N > 1 line proves by itself which devices the ranks sat on: one identity per rank (rank order), the world size the
+    process group saw, and the number of distinct devices (1 when the ranks of a rehearsal share the box's one GPU)."""
+    c = res["config"]
+    assert c["ranks_seen"] == world and len(c["gpus"]) == world
+    assert [g["rank"] for g in c["gpus"]] == list(range(world))
+    assert all("name" in g and "device_index" in g for g in c["gpus"])
+    assert c["gpu"] == c["gpus"][0]
+    assert c["distinct_gpus"] == (1 if shared else world)
 
 
 def check_c4_entry(res, world, backend):
@@ -69,6 +84,7 @@ def test_self_launched_two_ranks_share_the_gpu_over_gloo():
     assert abs(res["value"] - 2 * 16384 * 50 / (res["ms_per_step"] * 50e-3)) < 1e-3 * res["value"]
     assert len(res["ms_per_step_repeats"]) == 3 and sorted(res["ms_per_step_repeats"])[1] == pytest.approx(res["ms_per_step"], rel=1e-4)
     check_streaming_fields(res)
+    check_gpu_identities(res, 2, shared=True)
     check_c4_entry(res, 2, "gloo")
 
 
@@ -80,6 +96,7 @@ def test_self_launched_four_ranks_share_the_gpu_over_gloo():
     assert "extras" not in res
     assert res["n_gpus"] == 4 and len(res["roofline"]["kernel_ms_per_rank"]) == 4
     assert res["config"]["sharding"].startswith("env-shards x4")
+    check_gpu_identities(res, 4, shared=True)
     assert abs(res["value"] - 4 * 16384 * 30 / (res["ms_per_step"] * 30e-3)) < 1e-3 * res["value"]
 
 
@@ -103,6 +120,7 @@ def test_rccl_branch_runs_with_one_rank():
                                "--no-cpu-baseline", "--no-extras"))
     assert res["n_gpus"] == 1 and res["config"]["backend"] == "nccl" and len(res["roofline"]["kernel_ms_per_rank"]) == 1
     check_streaming_fields(res)
+    check_gpu_identities(res, 1, shared=False)
     check_c4_entry(res, 1, "nccl")                                    # the flat-bucket all-reduce through RCCL (one rank)
 
 
@@ -113,6 +131,24 @@ def test_rccl_two_ranks_when_two_gpus_are_visible():
         pytest.skip("needs two GPUs (the driver's multi-GPU node)")
     res = parse_line(run_bench("--gpus", "2", "--steps", "50", "--warmup", "5", "--repeats", "2", "--no-cpu-baseline", "--no-extras"))
     assert res["n_gpus"] == 2 and res["config"]["backend"] == "nccl"
+    check_gpu_identities(res, 2, shared=False)                         # two ranks on two DISTINCT devices, or bench.py exits
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_are_refused_without_share_device():
+    """Distinct devices are asserted: two ranks that land on the same GPU (here: forced by CUDA_VISIBLE_DEVICES-free LOCAL_RANK = 0 for
+    both) make bench.py exit instead of printing a line that looks like a 2-GPU measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "1",
+                               "--repeats", "1", "--no-cpu-baseline", "--no-extras", "--no-c4"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode != 0 for p in procs)
+    assert any("GPUs are not distinct" in e for _, e in outs) and all(o.strip() == "" for o, _ in outs)
 
 
 @pytest.mark.gpu

@@ -182,6 +182,14 @@ def test_agent_optimizer_is_a_handle_on_the_optimizer_that_steps():
     for g in opt.param_groups:                                            # the usual scheduler idiom
         g["lr"] = 1e-5
     assert agent.flat_adam.lr == pytest.approx(1e-5)
+    # the group is a real dict -- "lr" shows up wherever common optimizer code looks for it, and the dict is the source
+    # of truth for the learning rate FlatAdam steps with
+    g = opt.param_groups[0]
+    assert "lr" in g and "lr" in g.keys() and dict(g)["lr"] == pytest.approx(1e-5) and g.copy()["lr"] == pytest.approx(1e-5)
+    assert {k: v for k, v in g.items() if k != "params"}["lr"] == pytest.approx(1e-5)
+    assert g.setdefault("initial_lr", g["lr"]) == pytest.approx(1e-5) and g.setdefault("lr", 9.0) == pytest.approx(1e-5)
+    g.update(lr=2e-5)
+    assert agent.flat_adam.lr == pytest.approx(2e-5)
     with pytest.raises(RuntimeError):
         opt.step()
     agent.flat_adam.grad.normal_()
@@ -199,3 +207,7 @@ def test_agent_optimizer_is_a_handle_on_the_optimizer_that_steps():
     agent.flat_adam.grad.copy_(g2)
     agent.flat_adam.step()
     assert agent.flat_adam.steps == 2 and torch.equal(agent.flat_adam.flat, after_two)
+    # a state saved for other parameter shapes / another order is refused (the flat moments would land on the wrong weights)
+    bad = dict(sd, param_shapes=list(reversed(sd["param_shapes"])))
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad)
