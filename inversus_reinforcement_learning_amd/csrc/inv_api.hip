@@ -2,6 +2,9 @@
 //
 // gfx950 only.  One wavefront per env (see inv_device.h); 4 envs per 256-thread block, no
 // workgroup barriers.  Every entry point is asynchronous on the caller's stream.
+#if defined(INV_STEP_STAMPS) && !defined(INV_TOOLS_BUILD)
+#error "INV_STEP_STAMPS is a diagnostic build (in-kernel stamps): tools/build_variant.py only (it defines INV_TOOLS_BUILD)"
+#endif
 #include "inv_device.h"
 #include "inv_step4.h"
 #include "inv_internal.h"
@@ -221,8 +224,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_step(StepArgs a)
 #ifndef INV_ROLLOUT_MIN_WAVES
 #define INV_ROLLOUT_MIN_WAVES 4
 #endif
+// (the 32 x 32 instantiation needs ~140 registers: held to 128 by that bound it spilled 48 B/lane; it gets three waves per SIMD)
+#ifndef INV_ROLLOUT_MIN_WAVES_32
+#define INV_ROLLOUT_MIN_WAVES_32 3
+#endif
 template <class D, bool SINGLE, int WPB>
-__global__ __launch_bounds__(kWave * WPB, SINGLE ? 1 : INV_ROLLOUT_MIN_WAVES) void k_step4(StepArgs a)
+__global__ __launch_bounds__(kWave * WPB, SINGLE ? 1 : (D::W > 15 ? INV_ROLLOUT_MIN_WAVES_32 : INV_ROLLOUT_MIN_WAVES)) void k_step4(StepArgs a)
 {
     using namespace inv4;
     using LL = Lds4<D>;

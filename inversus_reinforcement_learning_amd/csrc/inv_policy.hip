@@ -24,6 +24,9 @@
 //
 // Numerics: bf16 operands, f32 accumulation, f32 LayerNorm, bf16 activations between layers -- NOT
 // bit-comparable with the f32 reference policy; tests bound the difference (tests/test_gpu_policy.py).
+#if defined(INV_POLICY_STAMPS) && !defined(INV_TOOLS_BUILD)
+#error "INV_POLICY_STAMPS is a diagnostic build (in-kernel stamps): tools/build_variant.py only (it defines INV_TOOLS_BUILD)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -36,14 +39,16 @@
 // library is built with -ffp-contract=off for the env / GAE kernels
 #pragma clang fp contract(fast)
 
+#if (defined(POL_BWD_NO_GEMM) || defined(POL_BWD_NO_DY) || defined(POL_BWD_NO_DZ) || defined(POL_BWD_NO_XLOAD)) && !defined(INV_TOOLS_BUILD)
+#error "POL_BWD_NO_* builds compute wrong gradients on purpose (timing probes): tools/build_variant.py only (it defines INV_TOOLS_BUILD)"
+#endif
+
 namespace pol {
 
 constexpr int H = 10, W = 15, P = H * W;                 // 150 pixels
 constexpr int PW = W + 2, PH = H + 2, NPOS = PW * PH;    // 12 x 17 haloed tile, 204 positions
 constexpr int OBS_WORDS = (12 * W * H + 31) / 32;          // 57 u32 words of one packed observation
-constexpr int CSTRIDE = 136;                             // bf16 per position: 128 channels + 8 pad = 272 B (POL_NO_ROWTILES builds)
-[[maybe_unused]] constexpr int kCStrideUnused = CSTRIDE;
-// Forward kernels (POL_ROWTILES): GEMM pixel tiles are BOARD ROWS (15 pixels + one dummy column that reads the right halo) on a
+// GEMM pixel tiles are BOARD ROWS (15 pixels + one dummy column that reads the right halo) on a
 // 288-B position stride.  ds_read_b128 is served in groups of 16 lanes that mix two channel groups (lanes 0-3, 12-15 of one,
 // 4-11 of the next): with consecutive positions 72 dwords (8 banks mod 64) apart and channel groups 4 dwords apart all sixteen
 // 16-B pieces of a group fall into different banks; a tile of 16 LINEAR pixels wraps to the next board row (a +2 position
@@ -51,13 +56,7 @@ constexpr int CSTRIDE = 136;                             // bf16 per position: 1
 // (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE in round 1).  Conflict-free reads are what lets a wave own 2 row blocks x
 // ALL 10 pixel tiles: every weight fragment is then loaded by ONE wave per workgroup instead of two (0.47 instead of 0.94 MB
 // per sample through the 64 B/clk vector memory path) at twice the (now half as expensive) activation fragment reads.
-#ifndef POL_NO_ROWTILES
-#define POL_ROWTILES 1
 constexpr int CSF = 144;                                 // forward: 288 B per position
-#else
-#define POL_ROWTILES 0
-constexpr int CSF = CSTRIDE;
-#endif
 constexpr int NPOSF = NPOS + 1;                          // the dummy column of the last board row reads one position past the halo
 constexpr int THREADS = 256, WAVES = THREADS / 64;       // 4 waves per block, 2 blocks per CU (55 KB LDS each)
 constexpr float LN_EPS = 1e-5f;
@@ -67,11 +66,7 @@ constexpr float LN_EPS = 1e-5f;
 // the loads to just before their first use (ds_read_b128 ... s_waitcnt lgkmcnt ... v_mfma on the same registers; weight
 // loads waited on two instructions after their issue), which leaves every wave latency-bound and the matrix pipe busy only
 // when a co-resident wave happens to fill the gaps.  A scheduling barrier after each group pins the written order.
-#ifndef POL_NO_PIN
 #define POL_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define POL_PIN() do { } while (0)
-#endif
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -150,13 +145,8 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     int pix[NW], base[NW], tap0[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-#if POL_ROWTILES
         pix[i] = (n0 + i) * W + min(c16, W - 1);                    // tile = board row n0 + i; column 15 is a dummy (never stored)
         base[i] = ((n0 + i + 1) * PW + c16 + 1) * CSF;              // the dummy column sits on the right halo: reads zeros
-#else
-        pix[i] = (n0 + i) * 16 + c16;
-        base[i] = pos_of(min(pix[i], P - 1)) * CSF;                 // columns >= 150 read pixel 149; never stored
-#endif
         tap0[i] = base[i] - (PW + 1) * CSF + 8 * kg;                // fragment address of tap (0,0), channel group 0
     }
 
@@ -171,10 +161,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     }
 
     const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
-#ifndef POL_AD
-#define POL_AD 3
-#endif
-    constexpr int AD = POL_AD;                                       // weight fragments are requested AD k-steps ahead (L2 latency)
+    constexpr int AD = 3;                                            // weight fragments are requested AD k-steps ahead (L2 latency; 2 and 4 measured equal)
     bf16x8 a[AD + 1][MW], b[NW];
 #pragma unroll
     for (int d = 0; d < AD; ++d)
@@ -226,18 +213,9 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     // (+ residual) and the LayerNorm statistics
     static_assert(!RAGGED, "tile ownership is 5 or 10 full-width tiles per wave");
     (void)ncount;
-#if POL_ROWTILES
     const bool vcol = c16 < W;                                       // the same for every tile of the lane
-    const float vlast = 1.0f;
-#else
-    const bool vcol = true;
-    const float vlast = pix[NW - 1] < P ? 1.0f : 0.0f;
-#endif
-    float s = 0.0f, ss = 0.0f;
-#ifndef POL_PK
-#define POL_PK 1
-#endif
-    // POL_PK: the sums run on accumulator PAIRS with v_pk_add_f32 / v_pk_fma_f32 (4 instructions per quad instead of 10; VALU issue,
+    float s, ss;
+    // the sums run on accumulator PAIRS with v_pk_add_f32 / v_pk_fma_f32 (4 instructions per quad instead of 10; VALU issue,
     // not LDS or latency, is what the knock-out probes show to be scarce).  Every instantiation sums in the same order.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 s2 = { 0.0f, 0.0f }, ss2 = { 0.0f, 0.0f };
@@ -252,23 +230,17 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
                 x0 += (float)rq[0]; x1 += (float)rq[1]; x2 += (float)rq[2]; x3 += (float)rq[3];
                 acc[mi][i][0] = x0; acc[mi][i][1] = x1; acc[mi][i][2] = x2; acc[mi][i][3] = x3;
             }
-            if (POL_PK && POL_ROWTILES) {
+            {
                 const f32x2 pa = { x0, x1 }, pb = { x2, x3 };
                 s2 += pa;
                 s2 += pb;
                 ss2 = __builtin_elementwise_fma(pa, pa, ss2);
                 ss2 = __builtin_elementwise_fma(pb, pb, ss2);
-                continue;
             }
-            // only the wave's LAST tile can hold columns past pixel 149 (150 = 9 x 16 + 6): every other tile is summed
-            // unconditionally and the last one through a 0 / 1 factor -- no exec-mask branch per tile (the per-tile `if`
-            // compiled to 20 s_and_saveexec / s_cbranch pairs with out-of-line bodies per layer and wave)
-            const float t1 = (x0 + x1) + (x2 + x3), t2 = fmaf(x0, x0, x1 * x1) + fmaf(x2, x2, x3 * x3);
-            if (i + 1 < NW) { s += t1; ss += t2; }
-            else { s = fmaf(vlast, t1, s); ss = fmaf(vlast, t2, ss); }
         }
     }
-    if (POL_PK && POL_ROWTILES) { s = s2[0] + s2[1]; ss = ss2[0] + ss2[1]; }
+    s = s2[0] + s2[1];
+    ss = ss2[0] + ss2[1];
     if (!vcol) { s = 0.0f; ss = 0.0f; }                              // row tiles: the dummy column's sums
     s = wave_sum(s);
     ss = wave_sum(ss);
@@ -297,7 +269,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             const int ch0 = (m0 + mi) * 16 + 4 * kg;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                if (POL_ROWTILES ? vcol : (i + 1 < NW || pix[i] < P)) {
+                if (vcol) {
                     bf16x4 xq;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xq[e] = (bf16)fmaf(acc[mi][i][e], rstd, shift);
@@ -330,10 +302,9 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             const int ch0 = (m0 + mi) * 16 + 4 * kg;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                if (POL_ROWTILES ? vcol : (i + 1 < NW || pix[i] < P)) {
+                if (vcol) {
                     bf16x4 o;
                     const f16x8 q = ln[mi][i];
-#if POL_PK
                     // pairs: x^ by one v_pk_fma_f32, ReLU AFTER the bf16 rounding as a signed 16-bit maximum with 0 on the packed pair
                     // (v_pk_max_i16: a negative bf16 is a negative int16; relu(round(x)) == round(relu(x))): 5 instead of 7 per pair
                     typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -358,16 +329,6 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
                         const bf16x2 r = __builtin_bit_cast(bf16x2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, yp), z2));
                         o[2 * h] = r[0]; o[2 * h + 1] = r[1];
                     }
-#else
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float xh = fmaf(acc[mi][i][e], rstd, shift);
-                        // TN (train numerics): x^ rounded to bf16 before the affine, the same operations on the same operands as the
-                        // training forward's row pass (SAVE) -- bit-identical features without its extra barrier and row pass
-                        if (TN) xh = (float)(bf16)xh;
-                        o[e] = (bf16)fmaxf(fmaf(xh, (float)q[e], (float)q[4 + e]), 0.0f);
-                    }
-#endif
                     // IN PLACE: every read of the input tile by the GEMM happened before the statistics barrier
                     // above, and the residual read of this lane's own elements precedes this write
                     *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
@@ -380,34 +341,8 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     STAMP(9 + layer);                                                // wait at the end-of-layer barrier (SAVE: whole epilogue)
 }
 
-// Stagger of the two workgroups that share a CU.  Both run the same program over equally long samples, so once started
-// together they stay in lockstep: both in their GEMMs (fighting for the SIMD's matrix pipe), then both in their
-// statistics / epilogue phases (pipe idle).  The second workgroup to arrive on a CU therefore starts POL_STAGGER cycles
-// late, which puts its GEMMs beside the other's epilogues (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Which
-// workgroups share a CU is not defined by HIP: the arrival order is read from a per-CU counter keyed by the hardware ids.
-// Speed only -- a wrong guess costs the delay once, results never depend on it.
-#ifndef POL_STAGGER
-#define POL_STAGGER 0
-#endif
-__device__ unsigned int g_cu_arrivals[16 * 256];
-
-__device__ __forceinline__ void stagger_second_workgroup(int tid, float *red)
-{
-    if (POL_STAGGER <= 0) return;
-    if (tid == 0) {
-        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: [11:8] CU, [12] SH, [15:13] SE
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);         // HW_REG_XCC_ID [3:0]
-        const uint32_t cu = ((hw >> 8) & 0xffu) | ((xcc & 15u) << 8);
-        reinterpret_cast<unsigned int *>(red)[0] = atomicAdd(&g_cu_arrivals[cu], 1u) & 1u;
-    }
-    __syncthreads();
-    const unsigned int second = reinterpret_cast<unsigned int *>(red)[0];
-    __syncthreads();
-    if (second) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)POL_STAGGER) __builtin_amdgcn_s_sleep(32);
-    }
-}
+// (A start-up stagger of the two workgroups that share a CU -- the second one 30 k / 55 k cycles late -- was measured in round 2: no
+// effect in either build, profiles/r02_trunk_ab_pin_stagger.log; removed.)
 
 // BITS: the observation arrives as the packed bitstring inv_step writes under INV_STEP_OBS_BITS (57 words per sample).
 // SAVE: training forward -- every layer also stores x^, its activation and rstd for k_policy_trunk_bwd.
@@ -432,7 +367,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
     }
     if (BITS && tid < OBS_WORDS && (int)blockIdx.x < N) obw[tid] = obits[(size_t)blockIdx.x * OBS_WORDS + tid];
     __syncthreads();
-    stagger_second_workgroup(tid, red);
 
     unsigned long long stamp_prev = 0;
 #ifdef INV_POLICY_STAMPS
@@ -506,27 +440,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
             float *const rs = sv.rstd + (size_t)n * 4;
             conv_ln_relu<32, 32, 1, 5, false, false, true>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0, LayerSave{ xh0, ac0, rs });
             conv_ln_relu<32, 64, 1, 10, false, false, true>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1, LayerSave{ xh1, ac1, rs + 1 });
-#if POL_ROWTILES
             conv_ln_relu<64, 128, 2, 10, false, false, true>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2, LayerSave{ xh2, ac2, rs + 2 });
             conv_ln_relu<128, 128, 2, 10, false, true, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3, LayerSave{ xh3, nullptr, rs + 3 });
-#else
-            conv_ln_relu<64, 128, 4, 5, false, false, true>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2, LayerSave{ xh2, ac2, rs + 2 });
-            conv_ln_relu<128, 128, 4, 5, false, true, true>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3, LayerSave{ xh3, nullptr, rs + 3 });
-#endif
         } else {
         conv_ln_relu<32, 32, 1, 5, false, false, false, TN>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
-#ifdef POL_CONV2_2x5
-        conv_ln_relu<32, 64, 2, 5, false, false, false, TN>(prm.layer[1], tile, red, lane_i, (wave & 1) * 2, (wave >> 1) * 5, 5, stamp_prev, 1);
-#else
         conv_ln_relu<32, 64, 1, 10, false, false, false, TN>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
-#endif
-#if POL_ROWTILES
         conv_ln_relu<64, 128, 2, 10, false, false, false, TN>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2);
         conv_ln_relu<128, 128, 2, 10, false, true, false, TN>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3);
-#else
-        conv_ln_relu<64, 128, 4, 5, false, false, false, TN>(prm.layer[2], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 2);
-        conv_ln_relu<128, 128, 4, 5, false, true, false, TN>(prm.layer[3], tile, red, lane_i, (wave & 1) * 4, (wave >> 1) * 5, 5, stamp_prev, 3);
-#endif
         }
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * P * 128);
@@ -887,12 +807,7 @@ __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int l
     int tap0[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-#if POL_ROWTILES
         tap0[i] = ((n0 + i + 1) * PW + c16 + 1) * CSF - (PW + 1) * CSF + 8 * kg;       // tile = board row, column 15 = right halo (zeros)
-#else
-        const int px = (n0 + i) * 16 + c16;
-        tap0[i] = pos_of(min(px, P - 1)) * CSF - (PW + 1) * CSF + 8 * kg;
-#endif
     }
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi)
@@ -972,13 +887,9 @@ __device__ __forceinline__ void bwd_request(BwdRegs<COUT> &rg, int bt, const voi
     }
 }
 
-// REQUESTED (POL_BWD_EARLY, off): batch 0 was requested by the caller from the epilogue of the transposed convolution above this
-// pass, after its last weight-fragment wait, so that the HBM round trip overlaps the accumulator write-back and its two barriers.
-// Measured 1.89 vs 1.85-1.87 ms without: the other workgroup of the CU already fills that gap.
-#ifndef POL_BWD_EARLY
-#define POL_BWD_EARLY 0
-#endif
-template <int COUT, bool FROM_GLOBAL, bool REQUESTED = false>
+// (Requesting batch 0 from the epilogue of the transposed convolution above this pass measured 1.89 vs 1.85-1.87 ms without: the other
+// workgroup of the CU already fills that gap; removed.)
+template <int COUT, bool FROM_GLOBAL>
 __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf16 *xhat_n, float rstd, const bf16 *da_n, bf16 *dy_n, bf16 *dz_n,
                                                  bf16 *tile, float *red, BwdRegs<COUT> &rg)
 {
@@ -1010,7 +921,7 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
             }
         }
     };
-    if (!REQUESTED) request(0);
+    request(0);
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) {
         if (bt + 1 < NB) request(bt + 1);
@@ -1085,21 +996,13 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
 #else
     conv_gemm<CIN_T, COUT_BELOW, MW, NW>(wt, tile, lane, m0, n0, acc);
 #endif
-#if POL_BWD_EARLY
-    bwd_request<COUT_BELOW>(next, 0, next_ln, next_xhat, (int)threadIdx.x);      // the GEMM's fragment registers are dead: first batch of the pass below
-    POL_PIN();
-#endif
     const int c16 = lane & 15, kg = lane >> 4;
     if (RESIDUAL) {                                  // z4 = conv4(a3) + b4 + a3: da3 += dz4 (this lane's own entries of the tile)
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-#if POL_ROWTILES
                 const int posi = (n0 + i + 1) * PW + c16 + 1;                                // dummy column: halo, zeros
-#else
-                const int posi = pos_of(min((n0 + i) * 16 + c16, P - 1));
-#endif
                 const bf16x4 r = *reinterpret_cast<const bf16x4 *>(tile + posi * CSF + (m0 + mi) * 16 + 4 * kg);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[mi][i][e] += (float)r[e];
@@ -1110,14 +1013,8 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-#if POL_ROWTILES
             const bool pv = c16 < W;
             const int posi = (n0 + i + 1) * PW + c16 + 1;
-#else
-            const int px = (n0 + i) * 16 + c16;
-            const bool pv = px < P;
-            const int posi = pos_of(min(px, P - 1));
-#endif
             if (pv) {
                 bf16x4 o;
 #pragma unroll
@@ -1142,7 +1039,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
     }
     __syncthreads();
-    constexpr bool EARLY = POL_BWD_EARLY != 0;
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         int lane_i = lane;
         asm volatile("" : "+v"(lane_i));
@@ -1155,18 +1051,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         BwdRegs<32> rc;
         ln_relu_bwd_rows<128, true>(prm.ln[3], xh3, rs.w, dfeat + sn * 128, reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128,
                                     reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red, ra);
-#if POL_ROWTILES
         conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0, ra, prm.ln[2], xh2);
-#else
-        conv_t_to_tile<128, 128, 4, 5, true>(prm.wt[2], tile, lane_i, (wave & 1) * 4, (wave >> 1) * 5, ra, prm.ln[2], xh2);
-#endif
-        ln_relu_bwd_rows<128, false, EARLY>(prm.ln[2], xh2, rs.z, nullptr, reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128,
+        ln_relu_bwd_rows<128, false>(prm.ln[2], xh2, rs.z, nullptr, reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128,
                                             reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128, tile, red, ra);
         conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0, rb, prm.ln[1], xh1);
-        ln_relu_bwd_rows<64, false, EARLY>(prm.ln[1], xh1, rs.y, nullptr, reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64,
+        ln_relu_bwd_rows<64, false>(prm.ln[1], xh1, rs.y, nullptr, reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64,
                                            reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64, tile, red, rb);
         conv_t_to_tile<64, 32, 1, 5, false>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5, rc, prm.ln[0], xh0);
-        ln_relu_bwd_rows<32, false, EARLY>(prm.ln[0], xh0, rs.x, nullptr, reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32,
+        ln_relu_bwd_rows<32, false>(prm.ln[0], xh0, rs.x, nullptr, reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32,
                                            reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32, tile, red, rc);
     }
 }
@@ -1981,11 +1873,6 @@ extern "C" int inv_policy_debug_stamps(unsigned long long *out16_host, int reset
 static int trunk_grid(int N)
 {
     const int cus = inv_cu_count();                  // of the current device (cached per device)
-#ifdef POL_GRID_PROBE
-    const char *e = getenv("POL_BLOCKS_X2");         // probe builds: resident workgroups per 2 CUs (4 = the shipped two per CU)
-    const int per2 = e ? atoi(e) : 4;
-    return N < per2 * cus / 2 ? N : per2 * cus / 2;
-#endif
     return N < 2 * cus ? N : 2 * cus;               // two resident 256-thread workgroups per CU (55 KB of LDS each), persistent over samples
 }
 

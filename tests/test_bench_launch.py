@@ -148,7 +148,8 @@ def test_two_ranks_on_one_device_are_refused_without_share_device():
                               cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode != 0 for p in procs)
-    assert any("GPUs are not distinct" in e for _, e in outs) and all(o.strip() == "" for o, _ in outs)
+    assert any("GPUs are not distinct" in e for _, e in outs)
+    assert not any(ln.startswith("{") for o, _ in outs for ln in o.splitlines())      # no JSON line that could pass for a 2-GPU measurement
 
 
 @pytest.mark.gpu

@@ -66,7 +66,8 @@ rows = [("vs_dummy easy 15x10 f32", 15, 10, "dummy", "easy", False, False, 1),
         ("32 DISTINCT buffers, hard 15x10 f32", 15, 10, "dummy", "hard", False, False, -32),
         ("16 DISTINCT buffers, selfplay 15x10 f32 P1+P2", 15, 10, "selfplay", "easy", True, False, -16),
         ("4 DISTINCT buffers, hard 32x32 f32", 32, 32, "dummy", "hard", False, False, -4),
-        ("rollout T=4 hard 32x32 f32", 32, 32, "dummy", "hard", False, False, 4)]
+        ("rollout T=4 hard 32x32 f32", 32, 32, "dummy", "hard", False, False, 4),
+        ("rollout T=8 hard 32x32 PACKED", 32, 32, "dummy", "hard", False, True, 8)]
 res = {}
 for name, *c in rows:
     if only and not any(o_ in name for o_ in only):
