@@ -115,21 +115,40 @@ def thread_placement():
 
 
 def cpu_baseline_child(difficulty):
-    """cpu_baseline() in a fresh process whose OpenMP runtime starts with OMP_PROC_BIND=close / OMP_PLACES=cores (the variables are
-    read once, when the runtime initialises -- too late in a process that has imported torch)."""
+    """cpu_baseline() in fresh processes whose OpenMP runtime starts with the binding under test (the variables are read once, when
+    the runtime initialises -- too late in a process that has imported torch).  The full set of figures under OMP_PROC_BIND=spread /
+    OMP_PLACES=cores (the job's threads on as many core complexes and memory channels as the affinity mask gives: the CPU's best
+    case here), and the all-threads figure alone under `close` (all threads on neighbouring cores of ONE complex) and unbound."""
     import subprocess
-    env = dict(os.environ)
-    env.setdefault("OMP_PROC_BIND", "close")
-    env.setdefault("OMP_PLACES", "cores")
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--difficulty", difficulty],
-                       env=env, capture_output=True, text=True, timeout=600)
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or not line:
-        return {"error": f"cpu baseline child failed (rc {r.returncode}): {r.stderr[-300:]}"}
-    return json.loads(line[-1])
+
+    def child(bind, quick):
+        env = dict(os.environ)
+        if bind is None:
+            env.pop("OMP_PROC_BIND", None); env.pop("OMP_PLACES", None)
+        else:
+            env["OMP_PROC_BIND"], env["OMP_PLACES"] = bind, "cores"
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--difficulty", difficulty] + (["--cpu-baseline-quick"] if quick else [])
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"cpu baseline child failed (rc {r.returncode}): {r.stderr[-300:]}"}
+        return json.loads(line[-1])
+
+    res = child("spread", False)
+    if "error" in res:
+        return res
+    by = {"spread": round(res["value"])}
+    for name, bind in (("close", "close"), ("unbound", None)):
+        q = child(bind, True)
+        by[name] = round(q["value"]) if "value" in q else q
+    res["all_threads_env_steps_per_s_by_binding"] = by
+    best = max((v for v in by.values() if isinstance(v, int)), default=res["value"])
+    res["value_binding"] = "spread"
+    res["best_binding_env_steps_per_s"] = best
+    return res
 
 
-def cpu_baseline(difficulty, budget_s=8.0):
+def cpu_baseline(difficulty, budget_s=8.0, quick=False):
     """The C oracle (bit-checked against the reference) on the host cores: same seeds, same action stream, same
     config; bounded sample.  Threads = what the job may use (affinity / cgroup quota, both reported), the output
     buffers are allocated once and first touched inside the OpenMP region (each thread faults in the pages it writes)."""
@@ -175,6 +194,9 @@ def cpu_baseline(difficulty, budget_s=8.0):
                 break
         return n * steps / dt
 
+    if quick:                                            # the all-threads figure alone (binding comparison)
+        v, steps = run(NUM_ENVS, cores, 2.5)
+        return {"value": v, "unit": "env-steps/s", "cores": cores, "placement": thread_placement()}
     v, steps = run(NUM_ENVS, cores, budget_s)
     v1, _ = run(NUM_ENVS, 1, 3.0)
     # one thread on a per-thread SLICE of the job (16 384 envs / 16 threads = 1 024 envs: 7.4 MB of observations instead of
@@ -625,6 +647,7 @@ def main():
                     help="skip the second timed loop (the same launches re-writing ONE output buffer); for profiling the headline loop alone, "
                          "so that a rocprofv3 average of k_step4 is the streaming launches only")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit; no GPU is touched")
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="(internal) with --cpu-baseline-only: the all-threads figure alone")
     ap.add_argument("--no-c4", action="store_true",
                     help="N > 1 only: skip the self-play PPO iteration (collector + fused update + gradient all-reduce) extra")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -636,7 +659,7 @@ def main():
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.difficulty)), flush=True)
+        print(json.dumps(cpu_baseline(args.difficulty, quick=args.cpu_baseline_quick)), flush=True)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:                 # no launcher: be the launcher (before any GPU call)
         raise SystemExit(spawn_ranks(args.gpus))
