@@ -209,10 +209,12 @@ struct Cursor {
     }
 };
 
-// LDS map (bytes).  X buffers: 32 KiB * (t & 1), rows 0-127 | 128-255 of the tile.  W buffers behind them at 64 KiB:
-//   W3 (forward, weight gradient): THREE of 32 KiB, K-tile t in buffer t % 3 -- all 160 KiB;
-//   otherwise (dfeat):             two, K-tile t in buffer t & 1, and a 4-KiB epilogue window per wave behind them.
-[[maybe_unused]] constexpr int LDS_X = 32768, LDS_W0 = 65536, LDS_W = 32768, LDS_WIN = LDS_W0 + 2 * LDS_W;
+// LDS map (bytes): NX buffers of X (32 KiB each: rows 0-127 | 128-255 of the tile), then NW buffers of W, K-tile t in buffer t % N:
+//   forward          NX 3, NW 2   X = feat streams from HBM: it gets the third buffer (requests four load segments ahead of their wait)
+//   weight gradient  NX 2, NW 3   W = feat streams from HBM: it gets it
+//   dfeat            NX 2, NW 2   + a 4-KiB epilogue window per wave (both operands are L2-resident)
+// = all 160 KiB of the CU in every mode.
+[[maybe_unused]] constexpr int LDS_BUF = 32768;
 
 template <int MODE>
 __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
     const int wr = wave >> 2, wc = wave & 3;             // wr = the wave's GROUP: rows 128 wr .. + 127 of the tile; columns 64 wc .. + 63
     constexpr bool WT = MODE == MODE_DW;                 // W operand K-strided: transposing reads
-    constexpr bool W3 = MODE != MODE_DFEAT;              // three W buffers + balanced requests; dfeat: two + the epilogue window
+    constexpr int NX = MODE == MODE_FWD ? 3 : 2, NW = MODE == MODE_DW ? 3 : 2;
+    constexpr uint32_t LDS_W0 = NX * LDS_BUF, LDS_WIN = (NX + NW) * LDS_BUF;      // LDS_WIN: dfeat only (128 KiB)
 
     // ---- DMA source offsets.  A half-tile is 16 pieces of 1 KiB (one wave-instruction each):
     //   K-contiguous operand: piece pc = rows 8 pc .. 8 pc + 7; this lane: row 8 pc + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
-    // cursors: the consumer (K-tile t), the X producer (t + 1) and the W producer (W3: t + 2; else t + 1)
+    // cursors: the consumer (K-tile t) and the two producers -- the operand with three buffers runs two K-tiles ahead, the other one
     Cursor<MODE> cons, px, pw;
     cons.start(a);
     px = cons;
@@ -293,12 +296,12 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rw, (__attribute__((address_space(3))) void *)(lds + LDS_W0 + (uint32_t)wslot * LDS_W + (uint32_t)h * HALF +
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rw, (__attribute__((address_space(3))) void *)(lds + LDS_W0 + (uint32_t)wslot * LDS_BUF + (uint32_t)h * HALF +
                                                                                                         (uint32_t)wave * 1024u + 8192u * j),
                                                          16, vw[j] + (h ? whalf : 0u), so, 0, 0);
     };
     auto req_x = [&](const Cursor<MODE> &c, int xslot) {                     // the group's own X half-tile: 4 requests
-        const uint32_t d = (uint32_t)xslot * LDS_X + (uint32_t)wr * HALF + (uint32_t)(wave & 3) * 1024u, so = (uint32_t)c.kt * 128u;
+        const uint32_t d = (uint32_t)xslot * LDS_BUF + (uint32_t)wr * HALF + (uint32_t)(wave & 3) * 1024u, so = (uint32_t)c.kt * 128u;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rx, (__attribute__((address_space(3))) void *)(lds + d + 4096u * j), 16, vx[j], so, 0, 0);
@@ -309,12 +312,20 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue: K-tile 0 complete (W3: W of K-tile 1 in flight)
+    // ---- prologue: K-tile 0 complete; the three-buffer operand's K-tile 1 in flight
     req_x(px, 0);
     req_w(pw, 0);
     px.advance(a);
     pw.advance(a);
-    if (W3) {
+    if (NX == 3) {
+        if (px.valid && !(FC1_KNOCK & 2)) {
+            req_x(px, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        px.advance(a);
+    } else if (NW == 3) {
         if (pw.valid && !(FC1_KNOCK & 2)) {
             req_w(pw, 1);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -396,19 +407,22 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
     // ---- main loop: one K-tile = two phases of [fragment reads + 4 DMA requests] s_barrier [32 MFMAs] s_barrier
     // Phase 0 reads all of W's fragments (both 32-column halves of the wave's tile stay in registers for the K-tile) and X rows 0-63;
     // phase 1 reads X rows 64-127.  Segments = barrier intervals; group 0 loads in segments 4 t and 4 t + 2, group 1 one later.
-    //   W3:    phase 0 requests the group's X half-tile of K-tile t + 1, phase 1 waits for W of t + 1 (requested a K-tile ago) and
-    //          requests W of t + 2 into the third W buffer; behind the last MFMA: wait for X of t + 1.  Every wait is vmcnt(4):
-    //          exactly the youngest request group stays in flight.  (The probes put a request at ~100 cycles of the issuing wave's
-    //          time: eight of them in one load segment made it twice as long as the partner's 32 MFMAs -- profiles/r04_fc1_knockouts.txt.)
-    //   dfeat: phase 0 requests W and X of K-tile t + 1 (two W buffers: nothing of t + 2 has a free slot yet); its operands come from
-    //          L2, and moving X's requests to phase 1 measured equal.
+    // Requests (four per load segment wherever an operand has three buffers -- a request costs its wave ~100 cycles of issue time, and
+    // eight of them in one load segment made that segment twice as long as the partner's 32 MFMAs, profiles/r04_fc1_knockouts.txt):
+    //   weight gradient (NW 3): phase 0 requests the group's X half-tile of K-tile t + 1; phase 1 waits vmcnt(4) = W of t + 1 (requested
+    //          a K-tile ago), then requests W of t + 2; behind the last MFMA vmcnt(4) = X of t + 1.
+    //   forward (NX 3): phase 0 requests W of K-tile t + 1; phase 1 requests the group's X of t + 2, then waits vmcnt(4) = X of t + 1
+    //          (requested a K-tile ago: the HBM stream gets four segments of flight) and W of t + 1 (two segments; it comes from L2).
+    //   dfeat (2 + 2): phase 0 requests W and X of K-tile t + 1 (nothing of t + 2 has a free slot yet); phase 1 waits vmcnt(4) = W,
+    //          behind the last MFMA vmcnt(0) = X.  Its operands come from L2, and moving X's requests to phase 1 measured equal.
     // Hazards:  a W buffer is re-filled >= 2 segments after its last fragment read (the readers' lgkmcnt waits and a barrier lie in
     // between); an X half-tile is re-filled by the group that read it, one barrier after that group's last read; a wave waits for its
     // own requests (counted vmcnt) at least one barrier before any wave reads them.
     bf16x8 xf[2][4], wf[2][4];
-    int xs = 0, ws = 0;                                   // X buffer (t & 1), W buffer (t % 3 | t & 1)
+    int xs = 0, ws = 0;                                   // X buffer (t % NX), W buffer (t % NW)
+    auto nxt = [](int v, int n, int d) { v += d; return v >= n ? v - n : v; };
     while (cons.valid) {
-        const lds_byte *const lx = lds + (uint32_t)xs * LDS_X, *const lw = lds + LDS_W0 + (uint32_t)ws * LDS_W;
+        const lds_byte *const lx = lds + (uint32_t)xs * LDS_BUF, *const lw = lds + LDS_W0 + (uint32_t)ws * LDS_BUF;
         const bool fresh = !(FC1_KNOCK & 1) || cons.kt == cons.it.kt0;       // probe 1: fragments stay what the first K-tile loaded
         // phase 0
         if (fresh) {
@@ -429,8 +443,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
             }
         }
         if (!(FC1_KNOCK & 2)) {
-            if (!W3 && pw.valid) req_w(pw, ws ^ 1);
-            if (px.valid) req_x(px, xs ^ 1);
+            if (NW == 2 && pw.valid) req_w(pw, ws ^ 1);                  // W of K-tile t + 1
+            if (NX == 2 && px.valid) req_x(px, xs ^ 1);                  // X of K-tile t + 1
         }
         seg();
         __builtin_amdgcn_s_setprio(1);
@@ -450,9 +464,19 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
                 xf[1][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lx + xb1 + (uint32_t)(4 + mt) * 2048u);
             }
         }
-        if (px.valid && !(FC1_KNOCK & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // W of K-tile t + 1 (its X may still fly)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (W3 && pw.valid && !(FC1_KNOCK & 2)) req_w(pw, ws == 0 ? 2 : ws - 1);                  // (t + 2) % 3 == (t - 1) % 3
+        if (NX == 3) {
+            // forward: X of K-tile t + 2 goes out first, then the wait for everything older: X of t + 1 (requested a K-tile ago) and
+            // W of t + 1 (phase 0).  W cannot wait until behind the MFMAs as X does in the other modes: W is read by BOTH groups, and
+            // group 0's phase 0 of K-tile t + 1 runs in the same segment as group 1's phase-1 MFMAs of K-tile t.
+            const bool more = px.valid && !(FC1_KNOCK & 2);
+            if (more) req_x(px, nxt(xs, 3, 2));
+            if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (px.valid && !(FC1_KNOCK & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // W of K-tile t + 1 (its X, requested after it, may still fly)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (NW == 3 && pw.valid && !(FC1_KNOCK & 2)) req_w(pw, nxt(ws, 3, 2));               // W of K-tile t + 2 into the buffer K-tile t - 1 left
+        }
         seg();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -462,15 +486,17 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[4 + mt][nt] = mfma(wf[ks][nt], xf[ks][mt], acc[4 + mt][nt]);
         __builtin_amdgcn_s_setprio(0);
-        if (W3 && pw.valid && !(FC1_KNOCK & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // X of K-tile t + 1 (W of t + 2 may still fly)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NX == 2) {                                                   // the group's own X of K-tile t + 1 (weight gradient: W of t + 2 may still fly)
+            if (NW == 3 && pw.valid && !(FC1_KNOCK & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         px.advance(a);
         pw.advance(a);
         if (cons.kt + 1 == cons.it.kt1) epilogue(cons.it);
         cons.advance(a);
         seg();
-        xs ^= 1;
-        ws = W3 ? (ws == 2 ? 0 : ws + 1) : ws ^ 1;
+        xs = nxt(xs, NX, 1);
+        ws = nxt(ws, NW, 1);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 #else

@@ -67,6 +67,14 @@ constexpr float LN_EPS = 1e-5f;
 // loads waited on two instructions after their issue), which leaves every wave latency-bound and the matrix pipe busy only
 // when a co-resident wave happens to fill the gaps.  A scheduling barrier after each group pins the written order.
 #define POL_PIN() __builtin_amdgcn_sched_barrier(0)
+// Timing probes of the banded forward (tools/band_knock_ab.sh; the results are WRONG on purpose): 1 no MFMAs, 2 no weight-fragment
+// reloads in the k loop, 4 no global loads in the band input pass, 8 no z write-back stores, 16 no B-fragment LDS reads in the k
+// loop, 32 no feature pass
+#ifndef POL_BAND_KNOCK
+#define POL_BAND_KNOCK 0
+#elif !defined(INV_TOOLS_BUILD)
+#error "POL_BAND_KNOCK builds compute wrong features on purpose (timing probes): tools/build_variant.py only (it defines INV_TOOLS_BUILD)"
+#endif
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -519,6 +527,11 @@ __device__ __forceinline__ void band_load_norm(bf16 *tile, const bf16 *__restric
             dsto[j] = q < ITEMS ? pos * CSF + part * 8 : -1;
             const int p = in[j] ? y * (G::PWB - 2) + x : 0;
             const size_t o = (size_t)p * CPREV + part * 8;
+            if (POL_BAND_KNOCK & 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { z[j][e] = (bf16)(float)(o & 3); l0[j][e] = (_Float16)1.0f; l1[j][e] = (_Float16)0.5f; }
+                continue;
+            }
             z[j] = *reinterpret_cast<const bf16x8 *>(zprev + o);
             const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_prev) + o * 2;
             l0[j] = *reinterpret_cast<const f16x8 *>(lq);
@@ -604,15 +617,23 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
         const int ksa = ks + AD < KS ? ks + AD : KS - 1;
         const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
         const int off_n = ((tapn / 3) * G::PWB + (tapn % 3)) * CSF + kcn * 32;
+        if (!(POL_BAND_KNOCK & 2) || ks == 0) {
 #pragma unroll
-        for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
+            for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
+        }
         POL_PIN();
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
 #pragma unroll
-            for (int mi = 0; mi < MW; ++mi)
-                acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
-            b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
+            for (int mi = 0; mi < MW; ++mi) {
+                if (POL_BAND_KNOCK & 1) {
+                    typedef unsigned int knock_u4 __attribute__((ext_vector_type(4)));
+                    asm volatile("" :: "v"(__builtin_bit_cast(knock_u4, a[ks % (AD + 1)][mi])), "v"(__builtin_bit_cast(knock_u4, b[i])));
+                } else {
+                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
+                }
+            }
+            if (!(POL_BAND_KNOCK & 16)) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
             POL_PIN();
         }
     }
@@ -652,7 +673,7 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
     asm volatile("" : "+v"(tid1));
     for (int q = tid1; q < R * WBc * C8; q += THREADS) {             // whole rows: consecutive threads, consecutive 16-B chunks
         const int pb = q / C8, part = q - pb * C8, rr = pb / WBc, x = pb - rr * WBc;
-        dst[q] = *reinterpret_cast<const bf16x8 *>(tile + ((rr + 1) * G::PWB + x + 1) * CSF + part * 8);
+        if (!(POL_BAND_KNOCK & 8)) dst[q] = *reinterpret_cast<const bf16x8 *>(tile + ((rr + 1) * G::PWB + x + 1) * CSF + part * 8);
     }
     __syncthreads();                                                 // the tile is rebuilt by the next band
     STAMP(slot0 + 3);                                                // z through the tile to global memory
@@ -760,7 +781,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 6] = rstd; sv.stats[(size_t)n * 8 + 7] = shift; }
         // features: relu(LN4(z4)), channels-last [P][128]
-        {
+        if (!(POL_BAND_KNOCK & 32)) {
             constexpr int ITEMS = G::P * 16, CH = 4;
             bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * G::P * 128);
 #pragma unroll 1
@@ -830,15 +851,23 @@ __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int l
         const int ksa = ks + AD < KS ? ks + AD : KS - 1;
         const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
         const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSF + kcn * 32;
+        if (!(POL_BAND_KNOCK & 2) || ks == 0) {
 #pragma unroll
-        for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
+            for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
+        }
         POL_PIN();
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
 #pragma unroll
-            for (int mi = 0; mi < MW; ++mi)
-                acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
-            b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
+            for (int mi = 0; mi < MW; ++mi) {
+                if (POL_BAND_KNOCK & 1) {
+                    typedef unsigned int knock_u4 __attribute__((ext_vector_type(4)));
+                    asm volatile("" :: "v"(__builtin_bit_cast(knock_u4, a[ks % (AD + 1)][mi])), "v"(__builtin_bit_cast(knock_u4, b[i])));
+                } else {
+                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
+                }
+            }
+            if (!(POL_BAND_KNOCK & 16)) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
             POL_PIN();
         }
     }

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Timing probes of the banded 32 x 32 forward (POL_BAND_KNOCK bits, csrc/inv_policy.hip): each variant library in its own process, two
+# alternations on one box.  Build first (CPU):
+#   for k in 1 2 4 8 16 32 3 12 63; do ONLY_SOURCES=inv_policy.hip,inv_api.hip,inv_heads.hip,inv_fc1.hip,inv_optim.hip,inv_gae.hip python tools/build_variant.py bandknock$k -DPOL_BAND_KNOCK=$k; done
+# usage (GPU): bash tools/band_knock_ab.sh > gpurun_out/band_knock.txt
+cd "$(dirname "$0")/.."
+for rep in 1 2; do
+  for v in shipped 1 2 4 8 16 32 3 12 63; do
+    if [ "$v" = shipped ]; then unset INVERSUS_HIP_LIB; else export INVERSUS_HIP_LIB=$PWD/tools/exp/lib_bandknock$v.so; fi
+    timeout -k 10 120 python - "$v" <<'PY' || exit 1
+import sys, torch
+sys.path.insert(0, ".")
+from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+torch.manual_seed(0)
+B = 16384
+f = FusedPolicy(InversusCNNPolicy(12, 32, 32, 4).cuda().eval())
+g = torch.randint(-2 ** 31, 2 ** 31 - 1, (B, 384), dtype=torch.int32, device="cuda") & torch.randint(-2 ** 31, 2 ** 31 - 1, (B, 384), dtype=torch.int32, device="cuda")
+for _ in range(2): f.features(g)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): f.features(g)
+e1.record(); torch.cuda.synchronize()
+print("knock", sys.argv[1], "banded forward ms", round(e0.elapsed_time(e1) / 5, 3), flush=True)
+PY
+  done
+done
