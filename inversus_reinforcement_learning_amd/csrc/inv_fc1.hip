@@ -143,12 +143,25 @@ __device__ __forceinline__ Item get_item(const Args &a, int seq)
 
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
+// Transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns of 16-bit elements, each lane receives a
+// column), as INLINE ASSEMBLY: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin form whenever a `buffer_load ... lds` is in
+// flight (the intrinsic carries no memory operand, so the waitcnt pass assumes it aliases every LDS-DMA write) -- one full drain of
+// the DMA queue per K-tile (seen in the weight-gradient kernel's ISA).  The assembler form is invisible to that pass; in exchange
+// the kernel waits for the results itself: tr_wait() before the first use.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
-__device__ __forceinline__ bf16x8 tr_frag(const lds_byte *lo_p, const lds_byte *hi_p)
+__device__ __forceinline__ s16x4 tr_read(const lds_byte *p)
 {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lo_p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(hi_p));
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+    return v;
+}
+// s_waitcnt lgkmcnt(0), tied to eight results so that nothing that reads them can be scheduled in front of it
+__device__ __forceinline__ void tr_wait(s16x4 (&v)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+}
+__device__ __forceinline__ bf16x8 tr_join(s16x4 lo, s16x4 hi)
+{
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 v = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
     return __builtin_bit_cast(bf16x8, v);
@@ -426,11 +439,14 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
         const bool fresh = !(FC1_KNOCK & 1) || cons.kt == cons.it.kt0;       // probe 1: fragments stay what the first K-tile loaded
         // phase 0
         if (fresh) {
+            s16x4 tlo[8], thi[8];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 if (WT) {
-                    wf[0][nt] = tr_frag(lw + wt_lo[0][nt], lw + wt_hi[0][nt]);
-                    wf[1][nt] = tr_frag(lw + wt_lo[1][nt], lw + wt_hi[1][nt]);
+                    tlo[nt] = tr_read(lw + wt_lo[0][nt]);
+                    thi[nt] = tr_read(lw + wt_hi[0][nt]);
+                    tlo[4 + nt] = tr_read(lw + wt_lo[1][nt]);
+                    thi[4 + nt] = tr_read(lw + wt_hi[1][nt]);
                 } else {
                     wf[0][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lw + wb0 + (uint32_t)nt * 2048u);
                     wf[1][nt] = *(const __attribute__((address_space(3))) bf16x8 *)(lw + wb1 + (uint32_t)nt * 2048u);
@@ -440,6 +456,15 @@ __global__ __launch_bounds__(THREADS, 2) void k_fc1_gemm(Args a)
             for (int mt = 0; mt < 4; ++mt) {
                 xf[0][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lx + xb0 + (uint32_t)mt * 2048u);
                 xf[1][mt] = *(const __attribute__((address_space(3))) bf16x8 *)(lx + xb1 + (uint32_t)mt * 2048u);
+            }
+            if (WT) {
+                tr_wait(tlo);
+                tr_wait(thi);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    wf[0][nt] = tr_join(tlo[nt], thi[nt]);
+                    wf[1][nt] = tr_join(tlo[4 + nt], thi[4 + nt]);
+                }
             }
         }
         if (!(FC1_KNOCK & 2)) {

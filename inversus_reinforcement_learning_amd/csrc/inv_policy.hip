@@ -490,7 +490,9 @@ struct BandGeo {
     static_assert(WB % 16 == 0 && HB % R == 0 && NT % 2 == 0 && NT <= 10, "band geometry");
 };
 
-// x^ w + b, ReLU, for 8 channels; l0 / l1: {weight x4 | bias x4} of channels 0..3 / 4..7
+// x^ w + b, ReLU, for 8 channels; l0 / l1: {weight x4 | bias x4} of channels 0..3 / 4..7.  (36 vector instructions per call.  A 28-
+// instruction form -- packed f32 FMAs for x^, v_fma_mix_f32 written out, the ReLU as a packed int16 max on the rounded pairs -- measured
+// the same 10.8 ms per 32 x 32 forward: the instruction count of this pass is not what bounds the kernel, profiles/r04_banded_probes.md.)
 __device__ __forceinline__ bf16x8 ln_relu8(const bf16x8 z, const f16x8 l0, const f16x8 l1, float rstd, float shift)
 {
     bf16x8 o;
@@ -1980,14 +1982,19 @@ extern "C" int inv_policy_trunk_banded(const inv_policy_params *params, const vo
     if (height != 32 || width != 32) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_trunk_banded: built for the 32 x 32 board (got %d x %d)", (int)width, (int)height);
     if (scratch_bytes < inv_policy_trunk_banded_scratch_bytes(height, width)) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_banded: scratch too small");
     if (N == 0) return INV_OK;
-    const int grid = trunk_grid(N);
+#if defined(POL_BAND_ONE_PER_CU) && defined(INV_TOOLS_BUILD)
+    // concurrency probe (tools/band_knock_ab.sh): 48 KiB of unused dynamic LDS leave room for ONE workgroup per CU, half the grid
+    const int grid = (trunk_grid(N) + 1) / 2, dyn_lds = 49152;
+#else
+    const int grid = trunk_grid(N), dyn_lds = 0;
+#endif
     inv_policy_band_saved none;
     memset(&none, 0, sizeof none);
     if (obs_is_bits)
-        hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+        hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, true>), dim3(grid), dim3(pol::THREADS), dyn_lds, (hipStream_t)stream, *params, obs,
                            reinterpret_cast<pol::bf16 *>(feat_bf16), reinterpret_cast<pol::bf16 *>(scratch), (int)N, none);
     else
-        hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+        hipLaunchKernelGGL((pol::k_policy_trunk_banded<32, 32, 4, false>), dim3(grid), dim3(pol::THREADS), dyn_lds, (hipStream_t)stream, *params, obs,
                            reinterpret_cast<pol::bf16 *>(feat_bf16), reinterpret_cast<pol::bf16 *>(scratch), (int)N, none);
     return launch_status("inv_policy_trunk_banded");
 }
