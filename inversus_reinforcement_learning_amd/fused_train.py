@@ -166,31 +166,46 @@ class _TrunkTrainFn(torch.autograd.Function):
             out = list(out)
             if len(out) != 16 or any(t.dtype != torch.float32 or not t.is_contiguous() for t in out):
                 raise ValueError("backward(out=...): 16 contiguous f32 tensors in parameter order")
-        with torch.cuda.device(dev):
-            rc = lib.inv_policy_trunk_bwd(C.byref(bp), C.byref(saved), _ptr(dfeat), C.byref(grads), n,
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        L.raise_for(rc, lib)
+        # The backward kernel runs in `parts` launches over consecutive sample ranges, and each range's LayerNorm reductions (HBM-bound:
+        # dy and x^ once, 3.4 GB in all; ONE launch for the four layers, ADDED straight into the module-layout gradients) go to a side
+        # stream as soon as its range is queued: the first range's reduction runs beside the second range's backward kernel, the last
+        # one's beside `mid` (the first Linear's weight-gradient GEMM) and the convolutions' weight gradients, which only read what the
+        # backward kernel wrote.  The main stream waits for the side stream before returning, so every tensor used there outlives its
+        # use.  INVERSUS_PG_STREAM=0: one stream; INVERSUS_BWD_PARTS=1: one launch (round 3's schedule).
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if os.environ.get("INVERSUS_PG_STREAM", "1") != "0" else main
+        parts = max(1, int(os.environ.get("INVERSUS_BWD_PARTS", "2")))
+        if side is main or n < 4096 * parts:
+            parts = 1
+        lng = L.InvPolicyLnGrads()
+        for i in range(4):
+            lng.gw[i], lng.gb[i] = out[4 * i + 2].data_ptr(), out[4 * i + 3].data_ptr()
+        lo = 0
+        for k in range(parts):
+            m = (n - lo) // (parts - k)
+            sv_k, gr_k = L.InvPolicySaved(), L.InvPolicyGrads()
+            for i in range(4):
+                off = lo * 150 * _COUT[i] * 2
+                sv_k.xhat[i], gr_k.dy[i], gr_k.dz[i] = saved.xhat[i] + off, grads.dy[i] + off, grads.dz[i] + off
+            for i in range(3):
+                sv_k.act[i] = saved.act[i] + lo * 150 * _COUT[i] * 2
+            sv_k.rstd = saved.rstd + lo * 16
+            with torch.cuda.device(dev):
+                rc = lib.inv_policy_trunk_bwd(C.byref(bp), C.byref(sv_k), C.c_void_p(dfeat.data_ptr() + lo * 19200 * 2), C.byref(gr_k), m,
+                                              C.c_void_p(main.cuda_stream))
+            L.raise_for(rc, lib)
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                with torch.cuda.device(dev):
+                    rc = lib.inv_policy_param_grads_all(C.byref(gr_k), C.byref(sv_k), C.byref(lng), _PG_SLICES if m >= 8192 else max(16, _PG_SLICES // 2), m,
+                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                L.raise_for(rc, lib)
+            lo += m
         x0 = torch.empty((n, 150, 16), dtype=torch.bfloat16, device=dev)              # channels-last layer-1 input, 12 -> 16 channels
         with torch.cuda.device(dev):
             rc = lib.inv_policy_obs_to_x0(_ptr(obs), 1 if ctx.bits else 0, _ptr(x0), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.raise_for(rc, lib)
-        # The LayerNorm reductions (HBM-bound: dy and x^ once, 3.4 GB; ONE launch for the four layers, added straight into the
-        # module-layout gradients) run on a side stream beside MFMA-bound work of the main stream that only reads what the
-        # backward kernel wrote: `mid` (the first Linear's weight-gradient GEMM) and the convolutions' weight gradients.  The main
-        # stream waits for the side stream before returning, so every tensor used there outlives its use.  INVERSUS_PG_STREAM=0:
-        # one stream.
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if os.environ.get("INVERSUS_PG_STREAM", "1") != "0" else main
-        if side is not main:
-            side.wait_stream(main)
-        lng = L.InvPolicyLnGrads()
-        for i in range(4):
-            lng.gw[i], lng.gb[i] = out[4 * i + 2].data_ptr(), out[4 * i + 3].data_ptr()
-        with torch.cuda.stream(side):
-            with torch.cuda.device(dev):
-                rc = lib.inv_policy_param_grads_all(C.byref(grads), C.byref(saved), C.byref(lng), _PG_SLICES, n,
-                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            L.raise_for(rc, lib)
         if mid is not None:
             mid()
         # weight gradients: the kernel's [Cout][9][CinP] blocks of the four layers in one zeroed scratch, converted to the module's

@@ -22,7 +22,9 @@ unset CFG LAUNCHES
 python3 tools/agent_update_profile.py --no-prof > $O/update_speed.json 2>/dev/null; cat $O/update_speed.json
 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d $O/kt_upd -- python3 tools/agent_update_profile.py --no-prof > $O/update_under_rocprof.json 2> $O/kt_upd.err; echo "kt update rc=$?"
 find $O/kt_upd -name "*kernel_stats.csv" | head -1 | xargs -I{} head -40 {} > $O/update_kernel_stats_top40.csv
-find $O/kt_upd -name "*marker_api_stats.csv" -o -name "*marker*stats.csv" | head -1 | xargs -I{} cp {} $O/update_marker_stats.csv 2>/dev/null; rm -rf $O/kt_upd
+find $O/kt_upd -type f | sed "s|$O/kt_upd/||" > $O/update_rocprof_files.txt
+M=$(find $O/kt_upd -name "*marker*stats*.csv" | head -1); [ -z "$M" ] && M=$(find $O/kt_upd -name "*marker*trace*.csv" | head -1)
+if [ -n "$M" ]; then head -200 "$M" > $O/update_marker_rows.csv; fi; rm -rf $O/kt_upd
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_col -- python3 tools/collector_profile.py --no-prof > $O/collector_under_rocprof.json 2> $O/kt_col.err; echo "kt collector rc=$?"
 find $O/kt_col -name "*kernel_stats.csv" | head -1 | xargs -I{} head -24 {} > $O/collector_kernel_stats_top24.csv; rm -rf $O/kt_col
 echo "Cijk rows: update $(grep -c Cijk $O/update_kernel_stats_top40.csv), collector $(grep -c Cijk $O/collector_kernel_stats_top24.csv)"
@@ -30,4 +32,4 @@ python3 tools/fc1_bench.py 16384 10 > $O/fc1_bench_vs_library.json 2>/dev/null; 
 python3 tools/c5_update_speed.py --no-torch > $O/c5_update_speed.json 2>/dev/null; tail -1 $O/c5_update_speed.json
 python3 -c "
 import json; d=json.load(open('$O/bench_easy_with_extras.json')); print(json.dumps({k:d[k] for k in ('value','ms_per_step','value_cache_resident','roofline')}, indent=0)[:1500]); print({k: (v if not isinstance(v, dict) else {a:b for a,b in list(v.items())[:6]}) for k, v in d.get('extras', {}).items()})" 2>&1 | cut -c1-3000
-cut -c1-160 $O/update_kernel_stats_top40.csv | head -16; cat $O/update_marker_stats.csv 2>/dev/null | head -8
+cut -c1-160 $O/update_kernel_stats_top40.csv | head -16; head -8 $O/update_marker_rows.csv 2>/dev/null; true
