@@ -171,10 +171,12 @@ class _TrunkTrainFn(torch.autograd.Function):
         # stream as soon as its range is queued: the first range's reduction runs beside the second range's backward kernel, the last
         # one's beside `mid` (the first Linear's weight-gradient GEMM) and the convolutions' weight gradients, which only read what the
         # backward kernel wrote.  The main stream waits for the side stream before returning, so every tensor used there outlives its
-        # use.  INVERSUS_PG_STREAM=0: one stream; INVERSUS_BWD_PARTS=1: one launch (round 3's schedule).
+        # use.  Measured (tools/bwd_parts_ab.py, profiles/r04_bwd_parts_ab.txt): 1, 2, 3 and 4 parts are all 6.6-6.7 ms per minibatch --
+        # the board runs these kernels at its power cap and an HBM-bound kernel beside an MFMA-bound one hides little -- so the default
+        # stays ONE launch.  INVERSUS_BWD_PARTS=k: k launches; INVERSUS_PG_STREAM=0: one stream.
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if os.environ.get("INVERSUS_PG_STREAM", "1") != "0" else main
-        parts = max(1, int(os.environ.get("INVERSUS_BWD_PARTS", "2")))
+        parts = max(1, int(os.environ.get("INVERSUS_BWD_PARTS", "1")))
         if side is main or n < 4096 * parts:
             parts = 1
         lng = L.InvPolicyLnGrads()
