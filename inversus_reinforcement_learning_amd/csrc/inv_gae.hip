@@ -19,7 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "../../include/inversus_hip.h"
+#include "inv_internal.h"
 
 namespace {
 
@@ -51,39 +54,47 @@ __device__ __forceinline__ float gae_step(float r, float v, float vnext, bool do
 //     dependent steps per wave, the carry handed on through one LDS word per column and a workgroup barrier;
 //   * a wave streams its A and ret = A + V rows out AFTER handing the carry on, i.e. while the next wave runs its steps.
 // T > 128 loops over tiles from the end; the carry stays in LDS.
-constexpr int kGaeT = 128, kGaeWaves = 8, kGaeRows = kGaeT / kGaeWaves, kGaeCols = 64, kGaeThreads = kGaeWaves * 64;
+// Round 4: COLS columns per block, 64 (lane = column) or 16.  With 16 the wave's 64 lanes are 16 columns x 4 SUB-SLICES of the wave's
+// 16 rows (4 rows each; every global access a 64-B row piece): the chain passes through the four sub-slices in turn, handed from one to
+// the next by a lane shuffle -- still 16 dependent steps per wave -- and N envs make N / 16 blocks instead of N / 64: 1 024 blocks at
+// N = 16 384 (four per CU: 4 x the loads in flight), 256 at N = 4 096 where 64-column blocks left three CUs in four idle.
+constexpr int kGaeT = 128, kGaeWaves = 8, kGaeRows = kGaeT / kGaeWaves, kGaeThreads = kGaeWaves * 64;
 
+template <int COLS>
 __global__ __launch_bounds__(kGaeThreads) void k_gae_per_env(const float *__restrict__ r, const float *__restrict__ v,
                                                               const uint8_t *__restrict__ done, int T, int N, float gamma,
                                                               float gl, const float *__restrict__ last_value,
                                                               float *__restrict__ adv, float *__restrict__ ret)
 {
-    __shared__ float carry[kGaeCols];
+    constexpr int SUB = 64 / COLS, RS = kGaeRows / SUB;         // sub-slices per wave, rows per sub-slice
+    static_assert(COLS * SUB == 64 && RS * SUB == kGaeRows, "column / sub-slice split");
+    __shared__ float carry[COLS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int col = blockIdx.x * kGaeCols + lane;
+    const int c = lane % COLS, sub = lane / COLS;
+    const int col = blockIdx.x * COLS + c;
     const bool col_ok = col < N;
     const int colc = col_ok ? col : N - 1;                      // clamped: out-of-range lanes load a valid column and never store
-    if (w == 0) carry[lane] = 0.0f;                             // last_gae = 0 (ppo_agent.py:141)
+    if (w == 0 && sub == 0) carry[c] = 0.0f;                    // last_gae = 0 (ppo_agent.py:141)
 
     for (int thi = T - 1; thi >= 0; thi -= kGaeT) {
         const int rows = min(kGaeT, thi + 1);
-        const int k0 = w * kGaeRows;                            // my first tile row
-        const int nr = max(0, min(kGaeRows, rows - k0));        // my rows in this tile (wave-uniform)
-        float rr[kGaeRows], vv[kGaeRows], e[kGaeRows];
-        uint32_t dd[kGaeRows];
-        const int tn = thi - k0 + 1;                            // the step after my latest row (<= T; may be < 1 for an idle wave)
+        const int k0 = w * kGaeRows + sub * RS;                 // my first tile row (row k <-> time step thi - k)
+        const int nr = max(0, min(RS, rows - k0));              // my rows in this tile
+        float rr[RS], vv[RS], e[RS];
+        uint32_t dd[RS];
+        const int tn = thi - k0 + 1;                            // the step after my latest row (<= T; may be < 1 for an idle lane)
         const float *vnp = (tn < T || !last_value) ? v + (size_t)min(max(tn, 0), T - 1) * N + colc : last_value + colc;
         float vnext = *vnp;
         if (tn >= T && !last_value) vnext = 0.0f;
         // branch-free: rows beyond the tile's end (only in a last, partial tile) load step 0 again and are never used -- a load
         // inside a conditional block makes hipcc drain vmcnt at the block's end, i.e. one memory round trip per row
 #pragma unroll
-        for (int j = 0; j < kGaeRows; ++j) {
+        for (int j = 0; j < RS; ++j) {
             const size_t idx = (size_t)max(thi - k0 - j, 0) * N + colc;
             rr[j] = r[idx]; vv[j] = v[idx]; dd[j] = done[idx];
         }
 #pragma unroll
-        for (int j = 0; j < kGaeRows; ++j) {
+        for (int j = 0; j < RS; ++j) {
             const float vn = j == 0 ? vnext : vv[j - 1];
             const float gv = gamma * vn;
             const float sum = rr[j] + gv;
@@ -96,21 +107,26 @@ __global__ __launch_bounds__(kGaeThreads) void k_gae_per_env(const float *__rest
         for (int p = 0; p < kGaeWaves; ++p) {
             if (p * kGaeRows >= rows) break;                    // block-uniform
             if (w == p) {
-                float last = carry[lane];
+                float last = carry[c];
 #pragma unroll
-                for (int j = 0; j < kGaeRows; ++j) {
-                    const float g2 = gl * last;
-                    const float cand = e[j] + g2;
-                    const float nl = dd[j] ? e[j] : cand;
-                    last = j < nr ? nl : last;
-                    e[j] = last;                                // e becomes A
+                for (int q = 0; q < SUB; ++q) {                 // the chain runs through the sub-slices in turn (every lane computes,
+                    float mine = last;                          // sub-slice q's result counts)
+#pragma unroll
+                    for (int j = 0; j < RS; ++j) {
+                        const float g2 = gl * mine;
+                        const float cand = e[j] + g2;
+                        const float nl = dd[j] ? e[j] : cand;
+                        mine = j < nr ? nl : mine;
+                        if (SUB == 1 || sub == q) e[j] = mine;  // e becomes A
+                    }
+                    last = SUB == 1 ? mine : __shfl(mine, c + COLS * q);
                 }
-                carry[lane] = last;
+                if (sub == 0) carry[c] = last;
             }
             __syncthreads();
             if (w == p && col_ok) {
 #pragma unroll
-                for (int j = 0; j < kGaeRows; ++j) {
+                for (int j = 0; j < RS; ++j) {
                     if (j < nr) {
                         const size_t idx = (size_t)(thi - k0 - j) * N + col;
                         adv[idx] = e[j]; ret[idx] = e[j] + vv[j];
@@ -151,7 +167,17 @@ extern "C" int inv_gae(const float *r, const float *v, const uint8_t *done, int3
     if (!r || !v || !done || !adv || !ret || T < 1 || N < 1) return INV_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (layout == INV_GAE_PER_ENV) {
-        hipLaunchKernelGGL(k_gae_per_env, dim3((N + kGaeCols - 1) / kGaeCols), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
+        // 64-column blocks (256-B row pieces) once they give at least every second CU a block; below that 16-column blocks. Measured
+        // (profiles/r04_gae_cols_ab.txt): N = 4 096: 5.1 vs 6.3 us (T = 128), 19.2 vs 20.0 us (T = 512); N = 16 384: 13.8 vs 8.3 us --
+        // 64-B row pieces cost more than the extra blocks bring as soon as the wide blocks fill the chip.
+        bool wide = N >= 32 * inv_cu_count();
+#ifdef INV_TOOLS_BUILD
+        if (const char *e = getenv("INV_GAE_COLS")) wide = atoi(e) == 64;              // tools/gae_cols_ab.sh
+#endif
+        if (wide)
+            hipLaunchKernelGGL(k_gae_per_env<64>, dim3((N + 63) / 64), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
+        else
+            hipLaunchKernelGGL(k_gae_per_env<16>, dim3((N + 15) / 16), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
     } else if (layout == INV_GAE_REFERENCE_FLAT) {
         const long long n = (long long)T * N;
         hipLaunchKernelGGL(k_gae_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r, v, done, n, gamma, gamma_lam, last_value, adv, ret);
