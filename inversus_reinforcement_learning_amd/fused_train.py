@@ -166,6 +166,11 @@ class _TrunkTrainFn(torch.autograd.Function):
             out = list(out)
             if len(out) != 16 or any(t.dtype != torch.float32 or not t.is_contiguous() for t in out):
                 raise ValueError("backward(out=...): 16 contiguous f32 tensors in parameter order")
+        x0 = torch.empty((n, 150, 16), dtype=torch.bfloat16, device=dev)              # channels-last layer-1 input, 12 -> 16 channels (queued FIRST:
+        # a 30-us kernel behind the side stream's reduction waits for that kernel's workgroups to drain -- 0.67 ms under rocprofv3)
+        with torch.cuda.device(dev):
+            rc = lib.inv_policy_obs_to_x0(_ptr(obs), 1 if ctx.bits else 0, _ptr(x0), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.raise_for(rc, lib)
         # The backward kernel runs in `parts` launches over consecutive sample ranges, and each range's LayerNorm reductions (HBM-bound:
         # dy and x^ once, 3.4 GB in all; ONE launch for the four layers, ADDED straight into the module-layout gradients) go to a side
         # stream as soon as its range is queued: the first range's reduction runs beside the second range's backward kernel, the last
@@ -204,10 +209,6 @@ class _TrunkTrainFn(torch.autograd.Function):
                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
                 L.raise_for(rc, lib)
             lo += m
-        x0 = torch.empty((n, 150, 16), dtype=torch.bfloat16, device=dev)              # channels-last layer-1 input, 12 -> 16 channels
-        with torch.cuda.device(dev):
-            rc = lib.inv_policy_obs_to_x0(_ptr(obs), 1 if ctx.bits else 0, _ptr(x0), n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        L.raise_for(rc, lib)
         if mid is not None:
             mid()
         # weight gradients: the kernel's [Cout][9][CinP] blocks of the four layers in one zeroed scratch, converted to the module's

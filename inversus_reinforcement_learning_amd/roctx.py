@@ -1,6 +1,12 @@
-"""roctx ranges around the phases of the training loop: `rocprofv3 --kernel-trace --marker-trace` then attributes
-kernels to collect / GAE / update instead of by kernel name only.  libroctx64.so is loaded through ctypes when it is there
-(/opt/rocm/lib); without it every call is a no-op -- nothing here is needed for results."""
+"""roctx ranges around the phases of the training loop so that a profiler can attribute kernels to collect / GAE /
+update instead of by kernel name only.  libroctx64.so (roctracer's) is loaded through ctypes when it is there (/opt/rocm/lib); without
+it every call is a no-op -- nothing here is needed for results.
+
+What this image's rocprofv3 does with them (round 4, profiles/r04_incidents.md): with libroctx64.so a `--kernel-trace --marker-trace`
+run completes but writes NO marker file (rocprofiler-sdk only sees ranges pushed through its own librocprofiler-sdk-roctx.so); with that
+library loaded here instead -- through ctypes, after torch has initialised HIP -- the one profiled run of tools/agent_update_profile.py
+stopped producing output and was killed by the 7-minute watchdog.  So the default stays libroctx64.so; INVERSUS_ROCTX_LIB names another
+library for whoever wants to try a different tool, and INVERSUS_NO_ROCTX=1 switches the ranges off."""
 import contextlib
 import ctypes as C
 import os
@@ -16,7 +22,10 @@ def _load():
     _tried = True
     if os.environ.get("INVERSUS_NO_ROCTX") == "1":
         return None
-    for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so"):
+    names = ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so")
+    if os.environ.get("INVERSUS_ROCTX_LIB"):
+        names = (os.environ["INVERSUS_ROCTX_LIB"],)
+    for name in names:
         try:
             lib = C.CDLL(name)
             lib.roctxRangePushA.argtypes = [C.c_char_p]
