@@ -54,10 +54,10 @@ __device__ __forceinline__ float gae_step(float r, float v, float vnext, bool do
 //     dependent steps per wave, the carry handed on through one LDS word per column and a workgroup barrier;
 //   * a wave streams its A and ret = A + V rows out AFTER handing the carry on, i.e. while the next wave runs its steps.
 // T > 128 loops over tiles from the end; the carry stays in LDS.
-// Round 4: COLS columns per block, 64 (lane = column) or 16.  With 16 the wave's 64 lanes are 16 columns x 4 SUB-SLICES of the wave's
-// 16 rows (4 rows each; every global access a 64-B row piece): the chain passes through the four sub-slices in turn, handed from one to
-// the next by a lane shuffle -- still 16 dependent steps per wave -- and N envs make N / 16 blocks instead of N / 64: 1 024 blocks at
-// N = 16 384 (four per CU: 4 x the loads in flight), 256 at N = 4 096 where 64-column blocks left three CUs in four idle.
+// Round 4: COLS columns per block, 64 (lane = column) or 32 (small N).  With 32 the wave's 64 lanes are 32 columns x 2 SUB-SLICES of the
+// wave's 16 rows (8 rows each; every global access a 128-B row piece): the chain passes through the sub-slices in turn, handed from one
+// to the next by a lane shuffle -- still 16 dependent steps per wave -- and N envs make N / 32 blocks instead of N / 64: 128 at N = 4 096,
+// where 64-column blocks left three CUs in four idle.  (16 columns x 4 sub-slices, 64-B pieces: never better than 32; tools builds only.)
 constexpr int kGaeT = 128, kGaeWaves = 8, kGaeRows = kGaeT / kGaeWaves, kGaeThreads = kGaeWaves * 64;
 
 template <int COLS>
@@ -167,17 +167,22 @@ extern "C" int inv_gae(const float *r, const float *v, const uint8_t *done, int3
     if (!r || !v || !done || !adv || !ret || T < 1 || N < 1) return INV_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (layout == INV_GAE_PER_ENV) {
-        // 64-column blocks (256-B row pieces) once they give at least every second CU a block; below that 16-column blocks. Measured
-        // (profiles/r04_gae_cols_ab.txt): N = 4 096: 5.1 vs 6.3 us (T = 128), 19.2 vs 20.0 us (T = 512); N = 16 384: 13.8 vs 8.3 us --
-        // 64-B row pieces cost more than the extra blocks bring as soon as the wide blocks fill the chip.
-        bool wide = N >= 32 * inv_cu_count();
+        // 64-column blocks (256-B row pieces) once they give at least every second CU a block; below that 32-column blocks (128-B
+        // pieces, twice the blocks).  Measured, us per launch for 64 / 32 / 16 columns (profiles/r04_gae_cols_ab.txt):
+        //   T = 128, N = 16 384: 8.24 / 8.53 / 13.9      T = 128, N = 131 072: 55.7 / 62.9 / 89.0
+        //   T = 128, N =  4 096: 6.25 / 5.16 / 5.17      T = 512, N =   4 096: 20.0 / 16.3 / 19.3
+        int cols = N >= 32 * inv_cu_count() ? 64 : 32;
 #ifdef INV_TOOLS_BUILD
-        if (const char *e = getenv("INV_GAE_COLS")) wide = atoi(e) == 64;              // tools/gae_cols_ab.sh
+        if (const char *e = getenv("INV_GAE_COLS")) cols = atoi(e);                      // tools/gae_kernel_time.py A/B
 #endif
-        if (wide)
+        if (cols == 64)
             hipLaunchKernelGGL(k_gae_per_env<64>, dim3((N + 63) / 64), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
-        else
+#ifdef INV_TOOLS_BUILD
+        else if (cols == 16)
             hipLaunchKernelGGL(k_gae_per_env<16>, dim3((N + 15) / 16), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
+#endif
+        else
+            hipLaunchKernelGGL(k_gae_per_env<32>, dim3((N + 31) / 32), dim3(kGaeThreads), 0, st, r, v, done, T, N, gamma, gamma_lam, last_value, adv, ret);
     } else if (layout == INV_GAE_REFERENCE_FLAT) {
         const long long n = (long long)T * N;
         hipLaunchKernelGGL(k_gae_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r, v, done, n, gamma, gamma_lam, last_value, adv, ret);
