@@ -30,7 +30,7 @@ def test_gae_golden(name):
     assert bits_eq(adv.cpu().numpy(), g[f"{name}_adv_env"]) and bits_eq(ret.cpu().numpy(), g[f"{name}_ret_env"])
 
 
-@pytest.mark.parametrize("T,N,pdone", [(128, 16384, 0.03), (37, 1000, 0.2), (128, 4096, 0.0), (5, 3, 1.0)])
+@pytest.mark.parametrize("T,N,pdone", [(128, 16384, 0.03), (37, 1000, 0.2), (128, 4096, 0.0), (5, 3, 1.0), (300, 77, 0.1), (129, 8191, 0.05), (200, 8200, 0.05)])
 def test_gae_vs_oracle_large(T, N, pdone):
     import torch
     from inversus_reinforcement_learning_amd.device_env import gae
