@@ -1955,14 +1955,18 @@ static int launch_trunk(const inv_policy_params *params, const void *obs, bool b
     if (!params || !obs || !feat_bf16 || N < 0 || !layers_ok(params))
         return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk: NULL params / obs / feat, a NULL layer tensor, or N < 0");
     if (N == 0) return INV_OK;
-    const int grid = trunk_grid(N);
+#if defined(POL_BAND_ONE_PER_CU) && defined(INV_TOOLS_BUILD)
+    const int grid = (trunk_grid(N) + 1) / 2, dyn_lds = 49152;               // concurrency probe: one workgroup per CU (as for the banded kernel)
+#else
+    const int grid = trunk_grid(N), dyn_lds = 0;
+#endif
     inv_policy_saved none;
     memset(&none, 0, sizeof none);
     if (bits)
-        hipLaunchKernelGGL((pol::k_policy_trunk<true, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+        hipLaunchKernelGGL((pol::k_policy_trunk<true, false>), dim3(grid), dim3(pol::THREADS), dyn_lds, (hipStream_t)stream, *params, obs,
                            reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, none);
     else
-        hipLaunchKernelGGL((pol::k_policy_trunk<false, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, obs,
+        hipLaunchKernelGGL((pol::k_policy_trunk<false, false>), dim3(grid), dim3(pol::THREADS), dyn_lds, (hipStream_t)stream, *params, obs,
                            reinterpret_cast<pol::bf16 *>(feat_bf16), (int)N, none);
     return launch_status("inv_policy_trunk");
 }
