@@ -9,8 +9,9 @@
 //
 // One kernel core for all three: a 256 x 256 output tile per 512-thread workgroup (8 waves = 2 x 4, a wave owns 128 x 64 = 8 x 4 MFMA
 // tiles = 128 accumulator registers), K-tiles of 64 streamed HBM / L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, no
-// VGPR round trip) in 16-KB half-tiles (X rows 0-127 / 128-255, W rows 0-127 / 128-255; two X buffers, three W buffers -- two plus
-// an epilogue window for dfeat -- = all 160 KiB of the CU).  A K-tile is two PHASES of [LDS fragment reads + four DMA requests]
+// VGPR round trip) in 16-KB half-tiles (X rows 0-127 / 128-255, W rows 0-127 / 128-255; five 32-KiB buffers: the operand that streams
+// from HBM gets three -- X in the forward, W in the weight gradient --, the other two; dfeat: 2 + 2 and an epilogue window -- = all
+// 160 KiB of the CU).  A K-tile is two PHASES of [LDS fragment reads + four DMA requests]
 // s_barrier [32 MFMAs] s_barrier, and waves 4-7 run ONE BARRIER BEHIND waves 0-3, so on every SIMD one wave computes while its
 // partner loads (the two waves of a SIMD are w and w + 4).  DMA requests stay in flight across the barriers (raw s_barrier, counted
 // vmcnt: every wait leaves exactly the youngest group of four requests outstanding).  The hazard table sits at the main loop.
