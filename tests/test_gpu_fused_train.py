@@ -274,3 +274,25 @@ def test_direct_gradients_equal_the_autograd_path():
         a, b = direct[off:off + q.numel()], flat[off:off + q.numel()]
         assert rel(a, b) < 1e-5, (tuple(q.shape), rel(a, b))
         off += q.numel()
+
+
+def test_backward_in_two_launches_gives_the_one_launch_gradients(monkeypatch):
+    """INVERSUS_BWD_PARTS=2 (fused_train.py: the backward kernel over two sample ranges, each range's LayerNorm reduction queued on
+    the side stream right behind it) against the default single launch: the same 16 trunk gradients up to the f32 atomics of the
+    reductions and of the weight-gradient kernels.  8 192 samples: the smallest batch the split applies to."""
+    import torch
+    from inversus_reinforcement_learning_amd.fused_train import FusedTrainPolicy, _trunk_params
+    n = 8192
+    pol = _policy(11)
+    gf, gb, x = _obs(n, seed=5)
+    ft = FusedTrainPolicy(pol)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    feat = ft.features(gb)
+    dfeat = (torch.randn(feat.shape, device="cuda", generator=g) * 1e-3).to(feat.dtype)
+    monkeypatch.setenv("INVERSUS_BWD_PARTS", "1")
+    one = torch.autograd.grad(ft.features(gb), _trunk_params(pol), dfeat)
+    monkeypatch.setenv("INVERSUS_BWD_PARTS", "2")
+    two = torch.autograd.grad(ft.features(gb), _trunk_params(pol), dfeat)
+    torch.cuda.synchronize()
+    for a, b, q in zip(two, one, _trunk_params(pol)):
+        assert rel(a, b) < 1e-5, (tuple(q.shape), rel(a, b))
