@@ -302,13 +302,6 @@ int  inv_policy_wgrad_to_module(const float *src, const inv_policy_conv_grads *o
 typedef struct { float *gw[4]; float *gb[4]; } inv_policy_ln_grads;
 int  inv_policy_param_grads_all(const inv_policy_grads *grads, const inv_policy_saved *saved, const inv_policy_ln_grads *out,
                                 int32_t slices, int32_t N, void *stream);
-/* Layer-major form of inv_policy_trunk_bwd + inv_policy_param_grads_all (round-4 experiment, fused_train.py: INVERSUS_BWD_LAYERS=1):
- * one launch per layer over all samples, the LayerNorm gradient sums kept in registers (no dy tensor, no reduction pass), the
- * gradient between layers through `scratch` (bf16 [2][N][150][128]).  Writes grads->dz[0..3] (grads->dy is not touched) and ADDS the
- * LayerNorm gradients into ln_grads (zeroed by the caller).  Same reference as inv_policy_trunk_bwd: autograd over
- * inversus_rl/policies.py:91-99 (ppo_agent.py:225-232). */
-int  inv_policy_trunk_bwd_layers(const inv_policy_bwd_params *params, const inv_policy_saved *saved, const void *dfeat_bf16,
-                                 const inv_policy_grads *grads, const inv_policy_ln_grads *ln_grads, void *scratch, int32_t N, void *stream);
 /* Batch reductions for the LayerNorm gradients of one layer, one pass over dy and xhat (bf16 [N][E], E = 150 * C):
  * partial[s][0][e] = sum dy*xhat, partial[s][1][e] = sum dy over the samples n = s (mod slices); f32 [slices][2][E], every
  * entry written.  Adding the slices gives the LayerNorm weight / bias gradients in [pixel][channel] order. */

@@ -885,34 +885,27 @@ __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int l
 
 // pass A + B of one layer.  FROM_GLOBAL: da comes from HBM (layer 4: dfeat) instead of the tile.
 // items (pixel, 8 channels) per thread of a layer with COUT channels; CH of them are in flight at once (12-16 registers each)
-template <int COUT, int NT = THREADS> struct BwdItems {
-    static constexpr int ITEMS = P * (COUT / 8), NIT = (ITEMS + NT - 1) / NT, CH = NIT < 5 ? NIT : 5;
+template <int COUT> struct BwdItems {
+    static constexpr int ITEMS = P * (COUT / 8), NIT = (ITEMS + THREADS - 1) / THREADS, CH = NIT < 5 ? NIT : 5;
 };
 
 // Registers of pass A that can be requested before the pass starts: x^ of all the thread's items (the first CH requested) and the
 // two LayerNorm parameter buffers of the batch pipeline.
-template <int COUT, int NT = THREADS> struct BwdRegs {
-    bf16x8 xc[BwdItems<COUT, NT>::NIT];
-    f16x8 l0[2][BwdItems<COUT, NT>::CH], l1[2][BwdItems<COUT, NT>::CH];
+template <int COUT> struct BwdRegs {
+    bf16x8 xc[BwdItems<COUT>::NIT];
+    f16x8 l0[2][BwdItems<COUT>::CH], l1[2][BwdItems<COUT>::CH];
 };
-
-// Per-thread LayerNorm weight / bias gradient sums of the thread's items (the layer-major backward below: a thread owns the same
-// items for every sample of its workgroup, so sum_n dy x^ and sum_n dy stay in registers and dy never becomes a tensor).
-template <int COUT, int NT = THREADS> struct BwdSums {
-    float gw[BwdItems<COUT, NT>::NIT][8], gb[BwdItems<COUT, NT>::NIT][8];
-};
-struct BwdNoSums {};
 
 // The global loads of batch `bt` of a layer's pass A (x^ from HBM, LayerNorm parameters from L2).
-template <int COUT, int NT = THREADS>
-__device__ __forceinline__ void bwd_request(BwdRegs<COUT, NT> &rg, int bt, const void *ln_packed, const bf16 *xhat_n, int tid_l)
+template <int COUT>
+__device__ __forceinline__ void bwd_request(BwdRegs<COUT> &rg, int bt, const void *ln_packed, const bf16 *xhat_n, int tid_l)
 {
-    constexpr int ITEMS = BwdItems<COUT, NT>::ITEMS, NIT = BwdItems<COUT, NT>::NIT, CH = BwdItems<COUT, NT>::CH;
+    constexpr int ITEMS = BwdItems<COUT>::ITEMS, NIT = BwdItems<COUT>::NIT, CH = BwdItems<COUT>::CH;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         const int k = bt * CH + j;
         if (k < NIT) {
-            const int q = min(tid_l + k * NT, ITEMS - 1);          // clamped: the tail threads re-load the last item and discard it
+            const int q = min(tid_l + k * THREADS, ITEMS - 1);     // clamped: the tail threads re-load the last item and discard it
 #ifdef POL_BWD_NO_XLOAD
             for (int e = 0; e < 8; ++e) rg.xc[k][e] = (bf16)(0.01f * (float)(q & 63));
 #else
@@ -927,19 +920,17 @@ __device__ __forceinline__ void bwd_request(BwdRegs<COUT, NT> &rg, int bt, const
 
 // (Requesting batch 0 from the epilogue of the transposed convolution above this pass measured 1.89 vs 1.85-1.87 ms without: the other
 // workgroup of the CU already fills that gap; removed.)
-template <int COUT, bool FROM_GLOBAL, class SUMS = BwdNoSums, int NT = THREADS>
+template <int COUT, bool FROM_GLOBAL>
 __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf16 *xhat_n, float rstd, const bf16 *da_n, bf16 *dy_n, bf16 *dz_n,
-                                                 bf16 *tile, float *red, BwdRegs<COUT, NT> &rg, SUMS *sums = nullptr)
+                                                 bf16 *tile, float *red, BwdRegs<COUT> &rg)
 {
-    constexpr int NWV = NT / 64;                                             // waves of the workgroup (red[]: 2 NWV floats)
-    constexpr bool HAS_SUMS = !__is_same(SUMS, BwdNoSums);                  // dy is summed here instead of being stored
     // A thread owns the same NIT items (pixel, 8 channels) in both passes.  Pass A is a two-stage pipeline over batches of CH
     // items: the global loads of batch b + 1 (x^, LayerNorm parameters, and da for the top layer) are requested before batch b
     // is consumed, and pass B re-uses the x^ and LayerNorm weights that pass A fetched (80 registers at COUT = 128; the GEMM's
     // registers are dead here) instead of loading them again.  (Requesting x^ even earlier, before the transposed convolution
     // that produces da, does not help: vmcnt retires in order, so the GEMM's first weight-fragment wait then also waits for the
     // HBM loads issued before it -- and 20-40 more live registers put the 2 x 10-tile GEMM into scratch: 2.45-2.70 vs 1.90 ms.)
-    constexpr int CH8 = COUT / 8, ITEMS = BwdItems<COUT, NT>::ITEMS, NIT = BwdItems<COUT, NT>::NIT, CH = BwdItems<COUT, NT>::CH;
+    constexpr int CH8 = COUT / 8, ITEMS = BwdItems<COUT>::ITEMS, NIT = BwdItems<COUT>::NIT, CH = BwdItems<COUT>::CH;
     constexpr int NB = (NIT + CH - 1) / CH;
     // (hipcc hoists this thread's item addresses -- sample-invariant LayerNorm parameter pointers of all four layers -- out of the
     // sample loop and spills 39 of those registers: 156 B/lane of scratch, written once before the loop and re-loaded once per
@@ -952,12 +943,12 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
     float s1 = 0.0f, s2 = 0.0f;
     bf16x8 dag[2][FROM_GLOBAL ? CH : 1];
     auto request = [&](int bt) {
-        bwd_request<COUT, NT>(rg, bt, ln_packed, xhat_n, tid);
+        bwd_request<COUT>(rg, bt, ln_packed, xhat_n, tid);
         if (FROM_GLOBAL) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int k = bt * CH + j;
-                if (k < NIT) dag[bt & 1][j] = reinterpret_cast<const bf16x8 *>(da_n)[min(tid + k * NT, ITEMS - 1)];
+                if (k < NIT) dag[bt & 1][j] = reinterpret_cast<const bf16x8 *>(da_n)[min(tid + k * THREADS, ITEMS - 1)];
             }
         }
     };
@@ -968,7 +959,7 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
         POL_PIN();
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int k = bt * CH + j, q = tid + k * NT;
+            const int k = bt * CH + j, q = tid + k * THREADS;
             if (k < NIT && q < ITEMS) {
                 const int p = q / CH8, part = q - p * CH8;
                 bf16 *tp = tile + pos_of(p) * CSF + part * 8;
@@ -986,14 +977,10 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
                     const float dxh = (float)dy[e] * g;  // from the ROUNDED dy: pass B recomputes exactly this value
                     s1 += dxh;
                     s2 += dxh * x;
-                    if constexpr (HAS_SUMS) {            // k_policy_param_grads_all's terms, from the same rounded dy and bf16 x^
-                        sums->gw[k][e] = fmaf((float)dy[e], x, sums->gw[k][e]);
-                        sums->gb[k][e] += (float)dy[e];
-                    }
                 }
                 gc[k] = gk;
 #ifndef POL_BWD_NO_DY
-                if constexpr (!HAS_SUMS) reinterpret_cast<bf16x8 *>(dy_n)[q] = dy;
+                reinterpret_cast<bf16x8 *>(dy_n)[q] = dy;
 #endif
                 *reinterpret_cast<bf16x8 *>(tp) = dy;
             }
@@ -1003,16 +990,16 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     const int lane = tid & 63, wave = tid >> 6;
-    if (lane == 0) { red[wave] = s1; red[NWV + wave] = s2; }
+    if (lane == 0) { red[wave] = s1; red[WAVES + wave] = s2; }
     __syncthreads();
     float S1 = 0.0f, S2 = 0.0f;
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) { S1 += red[w]; S2 += red[NWV + w]; }
+    for (int w = 0; w < WAVES; ++w) { S1 += red[w]; S2 += red[WAVES + w]; }
     const float inv_cnt = 1.0f / (float)(COUT * P);
     const float m1 = S1 * inv_cnt, m2 = S2 * inv_cnt;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {                      // same items as in pass A: this thread's own tile entries
-        const int q = tid + k * NT;
+        const int q = tid + k * THREADS;
         if (q < ITEMS) {
             const int p = q / CH8, part = q - p * CH8;
             bf16 *tp = tile + pos_of(p) * CSF + part * 8;
@@ -1031,19 +1018,17 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
 
 // transposed conv of the dz tile -> da of the layer below, written back into the tile as bf16 (channels 0 .. COUT_BELOW)
 template <int CIN_T, int COUT_BELOW, int MW, int NW, bool RESIDUAL>
-__device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int lane, int m0, int n0, bool active = true)
+__device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int lane, int m0, int n0, BwdRegs<COUT_BELOW> &next, const void *next_ln,
+                                               const bf16 *next_xhat)
 {
-    // active (wave-uniform): a wave without tiles of its own (the 512-thread layer-major kernel's 64 -> 32 layer) only keeps the barriers
     f32x4 acc[MW][NW];
-    if (active) {
 #ifdef POL_BWD_NO_GEMM
-        for (int mi = 0; mi < MW; ++mi) for (int i = 0; i < NW; ++i) for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.001f * (float)(lane + mi + i);
+    for (int mi = 0; mi < MW; ++mi) for (int i = 0; i < NW; ++i) for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.001f * (float)(lane + mi + i);
 #else
-        conv_gemm<CIN_T, COUT_BELOW, MW, NW>(wt, tile, lane, m0, n0, acc);
+    conv_gemm<CIN_T, COUT_BELOW, MW, NW>(wt, tile, lane, m0, n0, acc);
 #endif
-    }
     const int c16 = lane & 15, kg = lane >> 4;
-    if (RESIDUAL && active) {                        // z4 = conv4(a3) + b4 + a3: da3 += dz4 (this lane's own entries of the tile)
+    if (RESIDUAL) {                                  // z4 = conv4(a3) + b4 + a3: da3 += dz4 (this lane's own entries of the tile)
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
@@ -1055,21 +1040,19 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
             }
     }
     __syncthreads();                                 // every wave has finished reading the dz tile
-    if (active) {
 #pragma unroll
-        for (int mi = 0; mi < MW; ++mi)
+    for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const bool pv = c16 < W;
-                const int posi = (n0 + i + 1) * PW + c16 + 1;
-                if (pv) {
-                    bf16x4 o;
+        for (int i = 0; i < NW; ++i) {
+            const bool pv = c16 < W;
+            const int posi = (n0 + i + 1) * PW + c16 + 1;
+            if (pv) {
+                bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[mi][i][e];
-                    *reinterpret_cast<bf16x4 *>(tile + posi * CSF + (m0 + mi) * 16 + 4 * kg) = o;
-                }
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[mi][i][e];
+                *reinterpret_cast<bf16x4 *>(tile + posi * CSF + (m0 + mi) * 16 + 4 * kg) = o;
             }
-    }
+        }
     __syncthreads();
 }
 
@@ -1099,180 +1082,18 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         BwdRegs<32> rc;
         ln_relu_bwd_rows<128, true>(prm.ln[3], xh3, rs.w, dfeat + sn * 128, reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128,
                                     reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red, ra);
-        conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0);
+        conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0, ra, prm.ln[2], xh2);
         ln_relu_bwd_rows<128, false>(prm.ln[2], xh2, rs.z, nullptr, reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128,
                                             reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128, tile, red, ra);
-        conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0);
+        conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0, rb, prm.ln[1], xh1);
         ln_relu_bwd_rows<64, false>(prm.ln[1], xh1, rs.y, nullptr, reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64,
                                            reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64, tile, red, rb);
-        conv_t_to_tile<64, 32, 1, 5, false>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5);
+        conv_t_to_tile<64, 32, 1, 5, false>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5, rc, prm.ln[0], xh0);
         ln_relu_bwd_rows<32, false>(prm.ln[0], xh0, rs.x, nullptr, reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32,
                                            reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32, tile, red, rc);
     }
 }
 
-
-// Layer-major form of the backward (round 4, experiment behind INVERSUS_BWD_LAYERS=1): ONE layer per launch over all samples, the
-// gradient between layers through a bf16 scratch tensor.  What it buys: a thread owns the same (pixel, 8-channel) items for every
-// sample of its workgroup, so the LayerNorm weight / bias gradient sums of ONE layer (16 per item) fit in registers -- dy is never
-// written (1.73 GB) and k_policy_param_grads_all's pass over dy and x^ (3.46 GB) disappears; what it costs: 2.2 GB of gradients
-// between the layers, and ONE 512-thread workgroup per CU whose eight waves walk the phases in step (a thread then owns 5 items = 80 sums
-// at 128 channels; the first version -- 256 threads, 10 items, 160 sums -- needed 512 registers and spilled: 7.03 vs 6.67 ms per minibatch).
-constexpr int LB_THREADS = 512;                       // 8 waves, one workgroup per CU: 5 items and 80 sums per thread at 128 channels
-
-// buffer descriptor from wave-uniform values, made PROVABLY uniform (readfirstlane): otherwise hipcc wraps every buffer_load in a
-// waterfall loop.  Bytes past `bytes` read as zeros (the range check), which is what the ragged last batch of items relies on.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t lb_rsrc(const void *base, uint32_t bytes)
-{
-    const uint64_t b = (uint64_t)base;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-
-// One layer of the backward over ALL samples (see the block comment above).  Per sample:
-//   the sample's x^ and da are already in two LDS staging arrays -- every wave LDS-DMAs the 16-byte items of its own lanes, item
-//   q = tid + k NT at byte 16 q of the array, while the PREVIOUS sample's GEMM runs (no registers, one counted wait, no barrier: a
-//   wave reads only what it requested itself);
-//   [A] dy = da [x^ w + b > 0] into the tile, the block sums of dx^ = dy w and dx^ x^, and this layer's LayerNorm gradient terms
-//       dy x^, dy added to the thread's 16 sums per item;  the next sample's staging requests go out as soon as [A] has its operands
-//       in registers;
-//   [B] dz = rstd (dx^ - mean - x^ mean') to HBM and into the tile;  the transposed convolution on the tile;  da' to HBM.
-// The LayerNorm parameters of the thread's items are loaded ONCE per launch (the per-sample kernel re-reads 211 KB per sample from L2).
-template <int COUT, int COUT_BELOW, int NW, bool RESIDUAL>
-__global__ __launch_bounds__(LB_THREADS, 1) void k_policy_layer_bwd(const void *ln_packed, const void *wt, const bf16 *__restrict__ xhat, const float *__restrict__ rstd4,
-                                                                      int layer, const bf16 *__restrict__ da_in, bf16 *__restrict__ dz_out,
-                                                                      bf16 *__restrict__ da_out, float *__restrict__ gw, float *__restrict__ gb, int N)
-{
-    constexpr int NT = LB_THREADS, NWV = NT / 64, CH8 = COUT / 8, ITEMS = P * CH8, NIT = (ITEMS + NT - 1) / NT;
-    constexpr uint32_t SBYTES = (uint32_t)ITEMS * 16u;              // one staged tensor of one sample
-    extern __shared__ __attribute__((aligned(16))) unsigned char lb_lds[];
-    bf16 *const tile = reinterpret_cast<bf16 *>(lb_lds);                                          // [NPOSF][CSF]
-    unsigned char *const stx = lb_lds + NPOSF * CSF * 2, *const std_ = stx + NIT * NT * 16;       // staging: x^, da  (NIT * NT items each)
-    float *const red = reinterpret_cast<float *>(std_ + NIT * NT * 16);                          // [2][NWV]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
-    for (int i = tid; i < NPOSF * CSF / 8; i += NT) {               // halo stays zero for the life of the block
-        bf16x8 z;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
-        reinterpret_cast<bf16x8 *>(tile)[i] = z;
-    }
-    // this thread's items: LayerNorm parameters (once), gradient sums (all samples)
-    f16x8 l0[NIT], l1[NIT];
-    float sgw[NIT][8], sgb[NIT][8];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int q = min(tid + k * NT, ITEMS - 1);
-        const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_packed) + (size_t)q * 16;
-        l0[k] = *reinterpret_cast<const f16x8 *>(lq);
-        l1[k] = *reinterpret_cast<const f16x8 *>(lq + 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sgw[k][e] = sgb[k][e] = 0.0f;
-    }
-    auto stage = [&](int n) {                                       // this wave's items of sample n -> the staging arrays
-        const __amdgpu_buffer_rsrc_t rx = lb_rsrc(xhat + (size_t)n * P * COUT, SBYTES), rd = lb_rsrc(da_in + (size_t)n * P * COUT, SBYTES);
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const uint32_t o = (uint32_t)(k * NT + wave * 64) * 16u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(stx + o), 16, o + (uint32_t)lane * 16u, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void *)(std_ + o), 16, o + (uint32_t)lane * 16u, 0, 0, 0);
-        }
-    };
-    // the transposed convolution's MT x 10 tiles of 16 x 16 over the waves: wave -> (row block wave % MT, NW pixel tiles from (wave / MT) NW)
-    constexpr int MT = COUT_BELOW > 0 ? COUT_BELOW / 16 : 1, NG = 10 / NW;
-    const bool active = wave < MT * NG;
-    const int m0 = wave % MT, n0 = active ? (wave / MT) * NW : 0;
-    if ((int)blockIdx.x < N) stage(blockIdx.x);
-    __syncthreads();
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
-        int lane_i = lane;
-        asm volatile("" : "+v"(lane_i));
-        const size_t sn = (size_t)n * P;
-        const float rstd = rstd4[(size_t)n * 4 + layer];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my staging requests (and the previous sample's stores) are done
-        bf16x8 xc[NIT];
-        float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int q = tid + k * NT;
-            xc[k] = *reinterpret_cast<const bf16x8 *>(stx + (size_t)q * 16);
-            const bf16x8 da = *reinterpret_cast<const bf16x8 *>(std_ + (size_t)q * 16);
-            if (q < ITEMS) {
-                const int px = q / CH8, part = q - px * CH8;
-                bf16x8 dy;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x = (float)xc[k][e], g = (float)(e < 4 ? l0[k][e] : l1[k][e - 4]), bb = (float)(e < 4 ? l0[k][4 + e] : l1[k][e]);
-                    const float d = fmaf(x, g, bb) > 0.0f ? (float)da[e] : 0.0f;
-                    dy[e] = (bf16)d;
-                    const float dxh = (float)dy[e] * g;  // from the ROUNDED dy, as in ln_relu_bwd_rows
-                    s1 += dxh;
-                    s2 += dxh * x;
-                    sgw[k][e] = fmaf((float)dy[e], x, sgw[k][e]);
-                    sgb[k][e] += (float)dy[e];
-                }
-                *reinterpret_cast<bf16x8 *>(tile + pos_of(px) * CSF + part * 8) = dy;
-            }
-            POL_PIN();                                   // one item at a time: interleaved items cost ~25 live registers each
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the staging arrays have been read: refill them for the next sample
-        if (n + (int)gridDim.x < N) stage(n + gridDim.x);
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (lane == 0) { red[wave] = s1; red[NWV + wave] = s2; }
-        __syncthreads();
-        float S1 = 0.0f, S2 = 0.0f;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) { S1 += red[w]; S2 += red[NWV + w]; }
-        const float inv_cnt = 1.0f / (float)(COUT * P);
-        const float m1 = S1 * inv_cnt, m2 = S2 * inv_cnt;
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {                  // same items: this thread's own tile entries
-            const int q = tid + k * NT;
-            if (q < ITEMS) {
-                const int px = q / CH8, part = q - px * CH8;
-                bf16 *tp = tile + pos_of(px) * CSF + part * 8;
-                const bf16x8 dy = *reinterpret_cast<const bf16x8 *>(tp);
-                bf16x8 dz;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    dz[e] = (bf16)(rstd * ((float)dy[e] * (float)(e < 4 ? l0[k][e] : l1[k][e - 4]) - m1 - (float)xc[k][e] * m2));
-                reinterpret_cast<bf16x8 *>(dz_out + sn * COUT)[q] = dz;
-                *reinterpret_cast<bf16x8 *>(tp) = dz;
-            }
-        }
-        __syncthreads();                                 // dz tile complete (B operand of the transposed convolution); red[] reusable
-        if constexpr (COUT_BELOW > 0) {
-            conv_t_to_tile<COUT, COUT_BELOW, 1, NW, RESIDUAL>(wt, tile, lane_i, m0, n0, active);
-            constexpr int C8 = COUT_BELOW / 8, ITEMS_B = P * C8;
-            bf16x8 *dst = reinterpret_cast<bf16x8 *>(da_out + sn * COUT_BELOW);
-            for (int q = tid; q < ITEMS_B; q += NT) {                 // whole rows: consecutive threads, consecutive 16-B chunks
-                const int px = q / C8, part = q - px * C8;
-                dst[q] = *reinterpret_cast<const bf16x8 *>(tile + pos_of(px) * CSF + part * 8);
-            }
-            __syncthreads();                                          // the next sample's pass A rewrites the tile
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int q = tid + k * NT;
-        if (q < ITEMS) {
-            const int px = q / CH8, part = q - px * CH8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                atomicAdd(gw + (size_t)(part * 8 + e) * P + px, sgw[k][e]);
-                atomicAdd(gb + (size_t)(part * 8 + e) * P + px, sgb[k][e]);
-            }
-        }
-    }
-}
-
-template <int COUT>
-constexpr int lb_lds_bytes()
-{
-    constexpr int NT = LB_THREADS, ITEMS = P * (COUT / 8), NIT = (ITEMS + NT - 1) / NT;
-    return NPOSF * CSF * 2 + 2 * NIT * NT * 16 + 2 * (NT / 64) * 4;
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Weight gradient of one convolution:  dW[co][tap][ci] = sum_n sum_p dz[n][p][co] * x[n][p + tap][ci].
@@ -2377,46 +2198,6 @@ extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const i
     hipLaunchKernelGGL(pol::k_policy_trunk_bwd, dim3(trunk_grid(N)), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, *saved,
                        reinterpret_cast<const pol::bf16 *>(dfeat_bf16), *grads, (int)N);
     return launch_status("inv_policy_trunk_bwd");
-}
-
-// Layer-major backward (experiment, see k_policy_layer_bwd): four launches, dz and the LayerNorm gradients out, no dy.
-// scratch: bf16 [N][150][128] x 2 (the gradients between the layers, ping-pong).
-extern "C" int inv_policy_trunk_bwd_layers(const inv_policy_bwd_params *params, const inv_policy_saved *saved, const void *dfeat_bf16,
-                                           const inv_policy_grads *grads, const inv_policy_ln_grads *ln_grads, void *scratch, int32_t N, void *stream)
-{
-    if (!params || !saved || !dfeat_bf16 || !grads || !ln_grads || !scratch || N < 0)
-        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_bwd_layers: NULL argument or N < 0");
-    for (int l = 0; l < 4; ++l)
-        if (!params->ln[l] || !saved->xhat[l] || !grads->dz[l] || !ln_grads->gw[l] || !ln_grads->gb[l] || (l < 3 && !params->wt[l]))
-            return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_bwd_layers: NULL tensor for layer %d", l);
-    if (!saved->rstd) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_bwd_layers: NULL rstd");
-    if (N == 0) return INV_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const int grid = (trunk_grid(N) + 1) / 2;                              // one workgroup per CU
-    using pol::bf16;
-    bf16 *sA = reinterpret_cast<bf16 *>(scratch), *sB = sA + (size_t)N * pol::P * 128;
-    auto X = [&](int l) { return reinterpret_cast<const bf16 *>(saved->xhat[l]); };
-    auto DZ = [&](int l) { return reinterpret_cast<bf16 *>(grads->dz[l]); };
-    static bool attr_set[64] = { false };            // per device ordinal: the attribute belongs to the device's code object
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_layer_bwd<128, 128, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pol::lb_lds_bytes<128>());
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_layer_bwd<128, 64, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, pol::lb_lds_bytes<128>());
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_layer_bwd<64, 32, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, pol::lb_lds_bytes<64>());
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pol::k_policy_layer_bwd<32, 0, 10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, pol::lb_lds_bytes<32>());
-        if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "inv_policy_trunk_bwd_layers: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL((pol::k_policy_layer_bwd<128, 128, 10, true>), dim3(grid), dim3(pol::LB_THREADS), pol::lb_lds_bytes<128>(), st, params->ln[3], params->wt[2], X(3), saved->rstd, 3,
-                       reinterpret_cast<const bf16 *>(dfeat_bf16), DZ(3), sA, ln_grads->gw[3], ln_grads->gb[3], (int)N);
-    hipLaunchKernelGGL((pol::k_policy_layer_bwd<128, 64, 5, false>), dim3(grid), dim3(pol::LB_THREADS), pol::lb_lds_bytes<128>(), st, params->ln[2], params->wt[1], X(2), saved->rstd, 2,
-                       sA, DZ(2), sB, ln_grads->gw[2], ln_grads->gb[2], (int)N);
-    hipLaunchKernelGGL((pol::k_policy_layer_bwd<64, 32, 5, false>), dim3(grid), dim3(pol::LB_THREADS), pol::lb_lds_bytes<64>(), st, params->ln[1], params->wt[0], X(1), saved->rstd, 1,
-                       sB, DZ(1), sA, ln_grads->gw[1], ln_grads->gb[1], (int)N);
-    hipLaunchKernelGGL((pol::k_policy_layer_bwd<32, 0, 10, false>), dim3(grid), dim3(pol::LB_THREADS), pol::lb_lds_bytes<32>(), st, params->ln[0], nullptr, X(0), saved->rstd, 0,
-                       sA, DZ(0), nullptr, ln_grads->gw[0], ln_grads->gb[0], (int)N);
-    return launch_status("inv_policy_trunk_bwd_layers");
 }
 
 template <int CINP, int COUT, int MWW, int NBW, bool PF, class GEO = pol::WgGeo15>

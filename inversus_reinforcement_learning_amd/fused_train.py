@@ -187,14 +187,6 @@ class _TrunkTrainFn(torch.autograd.Function):
         lng = L.InvPolicyLnGrads()
         for i in range(4):
             lng.gw[i], lng.gb[i] = out[4 * i + 2].data_ptr(), out[4 * i + 3].data_ptr()
-        layer_major = os.environ.get("INVERSUS_BWD_LAYERS", "0") == "1"      # experiment: one launch per layer, LayerNorm sums in registers
-        if layer_major:
-            scratch_da = torch.empty((2, n, 150, 128), dtype=torch.bfloat16, device=dev)
-            with torch.cuda.device(dev):
-                rc = lib.inv_policy_trunk_bwd_layers(C.byref(bp), C.byref(saved), _ptr(dfeat), C.byref(grads), C.byref(lng), _ptr(scratch_da), n,
-                                                     C.c_void_p(main.cuda_stream))
-            L.raise_for(rc, lib)
-            parts = 0
         lo = 0
         for k in range(parts):
             m = (n - lo) // (parts - k)
