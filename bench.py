@@ -19,8 +19,11 @@ that keeps a rollout does, and a footprint the 256 MiB Infinity Cache cannot hol
 The same launches re-writing ONE 118 MB buffer (rounds 1-3's headline loop; memory-side-cache writes) are timed beside it and
 reported as `value_cache_resident` / `roofline.*_cache_resident`.
 
-Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (k_step4) from HIP events on
-the launch stream; `cpu_baseline` times the CPU oracle (test infrastructure, used here only as
+Rank 0 prints ONE JSON line -- except when the C4 extra runs (N > 1, or --force-dist): then the complete headline line is printed
+and flushed BEFORE the extra (the first multi-rank RCCL all-reduce of the PPO path cannot lose it), and the same line with the
+extra's result -- or "failed: ..." -- is printed again after it: the LAST line is the superset, both carry the same `value`, and
+the exit code is 0 either way (c4_guarded).  `roofline` is for the dominant kernel (k_step4) from HIP events on
+the launch stream (`frac` = single launches, `frac_multi_step` = inv_rollout, T steps per launch: SURVEY 8d's two figures); `cpu_baseline` times the CPU oracle (test infrastructure, used here only as
 the yardstick) on a bounded sample of the same workload, in a child process of its own (OpenMP binding set before the runtime starts).
 """
 import argparse
@@ -592,6 +595,116 @@ def c4_iteration(torch, np, dist, n, rank, world, off, backend, T=8):
             "replicas_identical_after_update": digest_ok}
 
 
+MULTI_T = 32
+
+
+def multi_step_kernel_ms(torch, b, difficulty, T=MULTI_T, launches=8):
+    """SURVEY 8(d)'s second figure: the multi-step persistent launch.  ONE inv_rollout launch does T vector steps of the headline's
+    env batch into a [T]-deep rollout buffer (T distinct 118 MB observation slots: an HBM stream, like the headline loop);
+    HIP events on the launch stream around `launches` such launches; -> kernel ms per VECTOR step, or None on failure
+    (best-effort: it must never cost the headline line)."""
+    try:
+        a1 = torch.stack([b.uniform_actions(4321, t) for t in range(T)])
+        o = b._alloc_out((T,), True, False, False, None)
+        for _ in range(2):
+            b.rollout(a1, out=o)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            b.rollout(a1, out=o)
+        e1.record()
+        torch.cuda.synchronize()
+        b.check()
+        ms = e0.elapsed_time(e1) / (launches * T)
+        del o, a1
+        torch.cuda.empty_cache()
+        return ms
+    except Exception as exc:                                                # pragma: no cover
+        print(f"multi_step_kernel_ms failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+        return None
+
+
+C4_DEADLINE_S = float(os.environ.get("INVERSUS_BENCH_C4_DEADLINE_S", "420"))
+
+
+def c4_guarded(torch, np, dist, n, rank, world, off, backend, res):
+    """Run c4_iteration so that it can neither lose the (already printed) headline line nor strand a rank:
+      * an exception on this rank becomes the string "failed: ..." and is announced to the other ranks through the process group's
+        key-value store (a TCP store, NOT a collective -- the other ranks may be inside one that will never complete);
+      * a watcher thread on every rank polls that key (and a hard deadline, INVERSUS_BENCH_C4_DEADLINE_S, default 420 s, well inside
+        the process group's own timeout): when another rank has failed, or the deadline passes while this rank still sits in the
+        extra, rank 0 prints the line with the failure recorded and the process leaves with exit code 0 via os._exit (the main
+        thread may be blocked inside RCCL / gloo and cannot be unwound).
+    -> (c4 dict | "failed: ..." string, clean: every rank completed).
+    INVERSUS_BENCH_FAIL_C4 injects faults for tests/test_bench_launch.py: "1" = every rank raises, "rank<k>" = rank k raises,
+    "hang<k>" = rank k never enters the extra (sleeps)."""
+    import threading
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:                                                       # pragma: no cover
+        store = None
+    key = "inversus_bench_c4_failed"
+    done = threading.Event()
+    print_lock = threading.Lock()
+
+    def bail(reason):
+        with print_lock:
+            if done.is_set():
+                return
+            if rank == 0 and res is not None:
+                res.setdefault("extras", {})["C4 selfplay PPO iteration"] = f"failed: {reason}"
+                print(json.dumps(res), flush=True)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+
+    def watch():
+        t_end = time.time() + C4_DEADLINE_S
+        while not done.wait(1.0):
+            if time.time() > t_end:
+                bail(f"watchdog: rank {rank} still inside the C4 extra after {C4_DEADLINE_S:.0f} s")
+            if store is not None:
+                try:
+                    if store.check([key]):
+                        bail("another rank failed: " + store.get(key).decode(errors="replace"))
+                except Exception as exc:                                    # the store lives in rank 0: gone = rank 0 has left
+                    bail(f"rank {rank}: the process group's store went away ({type(exc).__name__})")
+
+    threading.Thread(target=watch, daemon=True).start()
+    fault = os.environ.get("INVERSUS_BENCH_FAIL_C4", "")
+    try:
+        torch.cuda.empty_cache()
+        if fault == "1" or fault == f"rank{rank}":
+            raise RuntimeError(f"injected failure on rank {rank} (INVERSUS_BENCH_FAIL_C4={fault})")
+        if fault == f"hang{rank}":
+            time.sleep(10 * C4_DEADLINE_S)
+        c4 = c4_iteration(torch, np, dist, n, rank, world, off, backend)
+        torch.cuda.empty_cache()
+        # every rank is through: agree on it without a collective that a failed peer could block (store counter)
+        if store is not None and world > 1:
+            store.add("inversus_bench_c4_ok", 1)
+            while int(store.add("inversus_bench_c4_ok", 0)) < world:
+                if store.check([key]):
+                    raise RuntimeError("another rank failed: " + store.get(key).decode(errors="replace"))
+                time.sleep(0.05)
+        with print_lock:
+            done.set()
+        return c4, True
+    except Exception as exc:
+        msg = f"{type(exc).__name__}: {exc}"[:2000]
+        with print_lock:
+            done.set()
+        if store is not None:
+            try:
+                store.set(key, f"rank {rank}: {msg}")
+            except Exception:                                               # pragma: no cover
+                pass
+        print(f"rank {rank}: C4 extra failed: {msg}", file=sys.stderr, flush=True)
+        if rank == 0 and world > 1:
+            time.sleep(3.0)                                                 # the store lives here: let the other ranks read the key first
+        return f"failed: {msg}", False
+
+
 def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks of this script (one per GPU) and wait.
     The parent has not imported torch or touched the GPU, and it never execs: the children are new processes that
@@ -681,6 +794,8 @@ def main():
     torch.cuda.set_device(dev)
     use_dist = world > 1 or args.force_dist
     if use_dist:
+        import datetime
+        PG_TIMEOUT = datetime.timedelta(seconds=900)                       # bounded: a collective that cannot complete ends the job, never hangs it
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:                               # only a forced one-rank group gets here without one
             from inversus_reinforcement_learning_amd.parallel import free_port
@@ -688,9 +803,9 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=PG_TIMEOUT)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=PG_TIMEOUT)
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     n = NUM_ENVS
@@ -789,18 +904,9 @@ def main():
         cdt, ckern_ms = median_region(cregions)
         ckern_ms_ranks = gather(ckern_ms)
 
-    # N > 1 (or a forced one-rank group): C4's self-play PPO iteration with the gradient all-reduce, on every rank
-    c4 = None
-    if use_dist and not args.no_c4:
-        torch.cuda.empty_cache()
-        try:
-            c4 = c4_iteration(torch, np, dist, n, rank, world, off, args.backend)
-        except Exception as exc:                                            # never lose the headline line to the extra
-            c4 = f"failed: {type(exc).__name__}: {exc}"
-            if world > 1:
-                raise
-        torch.cuda.empty_cache()
-
+    # ---- the headline line is complete HERE, before the first multi-rank collective of the PPO path runs (round-5 order: the C4 extra
+    # used to sit between the measured value and its only print) ----
+    res = None
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_env_step() * n
         kern_ms_roof = sorted(kern_ms_ranks)[len(kern_ms_ranks) // 2]
@@ -847,6 +953,16 @@ def main():
                 "traffic_cache_resident": traffic_from_profiles(args.difficulty),
                 "regime_cache_resident": "one 118 MB output buffer re-written per step: memory-side-cache (Infinity Cache) writes -- its "
                                          "'fraction of 8 TB/s' is NOT an HBM fraction"})
+    if world == 1:
+        # SURVEY 8(d)'s SECOND number -- the multi-step persistent launch (inv_rollout: T steps per launch) -- inside `roofline`, so that it
+        # survives a parser that keeps the contract's keys only
+        ms_multi = multi_step_kernel_ms(torch, b, args.difficulty)
+        if rank == 0 and ms_multi is not None:
+            am = algorithmic_bytes_per_env_step() * n / (ms_multi * 1e-3) / 1e9
+            res["roofline"].update({"kernel_ms_multi_step": ms_multi, "achieved_multi_step": am, "frac_multi_step": am / HBM_PEAK_GBS,
+                                    "regime_multi_step": f"inv_rollout: {MULTI_T} steps per launch into a [T] rollout buffer of f32 observations "
+                                                         "(HIP events around whole launches / T)"})
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:       # reported at N = 1 only (the other ranks would sit in the barrier)
             res["cpu_baseline"] = cpu_baseline_child(args.difficulty)
         if not args.no_extras and world == 1:
@@ -856,8 +972,22 @@ def main():
             two = res["extras"].get("two independent env shards of 8192 on two HIP streams (vs_dummy_easy 15x10 f32, wall clock per full 16384-env step)")
             if isinstance(two, dict):                                     # also inside `roofline`, so that it survives a parser that keeps the contract's keys
                 res["roofline"]["two_shards_on_two_streams"] = two
-        if c4 is not None:
+
+    # N > 1 (or a forced one-rank group): C4's self-play PPO iteration with the gradient all-reduce, on every rank -- AFTER rank 0 has
+    # printed and flushed the complete headline line.  A successful extra prints the superset line again (the last line wins); a failed
+    # or hung one prints the line with "failed: ..." in its place and every rank leaves with exit code 0 (never a bare raise that
+    # strands the other ranks in a collective: c4_guarded).
+    if use_dist and not args.no_c4:
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        c4, clean = c4_guarded(torch, np, dist, n, rank, world, off, args.backend, res)
+        if rank == 0:
             res.setdefault("extras", {})["C4 selfplay PPO iteration"] = c4
+            print(json.dumps(res), flush=True)
+        if not clean:                                                       # a rank failed: the group's collectives cannot be trusted to return
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+    elif rank == 0:
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

@@ -19,11 +19,18 @@ def run_bench(*flags, env_extra=None, timeout=600):
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
-def parse_line(proc):
+def parse_line(proc, with_c4=False):
+    """ONE JSON line from rank 0 -- or, when the C4 extra runs, the headline line first (printed and flushed BEFORE the extra) and the
+    superset line last: same headline fields in both, the last one is the result."""
     assert proc.returncode == 0, proc.stderr[-3000:]
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, proc.stdout[-2000:]                       # ONE JSON line, from rank 0 only
-    return json.loads(lines[0])
+    lines = [json.loads(ln) for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == (2 if with_c4 else 1), proc.stdout[-2000:]
+    if with_c4:
+        first, last = lines
+        assert "C4 selfplay PPO iteration" not in first.get("extras", {})
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "config"):
+            assert first[k] == last[k], k
+    return lines[-1]
 
 
 def check_streaming_fields(res):
@@ -75,10 +82,23 @@ def test_self_launch_fails_cleanly_without_gpus():
 
 
 @pytest.mark.gpu
+def test_single_gpu_line_carries_both_rooflines_of_survey_8d():
+    """N = 1: ONE line; `roofline` holds the single-launch figure (frac, kernel_ms) AND the multi-step persistent one
+    (inv_rollout, T steps per launch: frac_multi_step, kernel_ms_multi_step) -- SURVEY 8(d) asks for both."""
+    res = parse_line(run_bench("--steps", "60", "--warmup", "5", "--repeats", "2", "--no-cpu-baseline", "--no-extras"))
+    r = res["roofline"]
+    check_streaming_fields(res)
+    assert r["kernel_ms_multi_step"] > 0
+    assert r["achieved_multi_step"] == pytest.approx(7369 * 16384 / (r["kernel_ms_multi_step"] * 1e-3) / 1e9, rel=1e-6)
+    assert r["frac_multi_step"] == pytest.approx(r["achieved_multi_step"] / r["peak"], rel=1e-9)
+    assert 0.2 < r["frac_multi_step"] < 1.0 and "inv_rollout" in r["regime_multi_step"]
+
+
+@pytest.mark.gpu
 def test_self_launched_two_ranks_share_the_gpu_over_gloo():
     """`python bench.py --gpus 2` WITHOUT torchrun: two fresh child ranks (sharing the one GPU of the box over gloo)."""
     res = parse_line(run_bench("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "50", "--warmup", "5",
-                               "--repeats", "3", "--no-cpu-baseline", "--no-extras"))
+                               "--repeats", "3", "--no-cpu-baseline", "--no-extras"), with_c4=True)
     assert res["n_gpus"] == 2 and res["steps"] == 50 and res["scaling"] == "weak" and res["repeats"] == 3
     assert len(res["roofline"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in res["roofline"]["kernel_ms_per_rank"])
     assert abs(res["value"] - 2 * 16384 * 50 / (res["ms_per_step"] * 50e-3)) < 1e-3 * res["value"]
@@ -86,6 +106,24 @@ def test_self_launched_two_ranks_share_the_gpu_over_gloo():
     check_streaming_fields(res)
     check_gpu_identities(res, 2, shared=True)
     check_c4_entry(res, 2, "gloo")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fault", ["1", "rank1", "rank0", "hang1"])
+def test_a_failing_c4_extra_cannot_lose_the_headline_line(fault):
+    """Round 5 (verdict 1): the headline line is printed and flushed BEFORE the C4 extra -- the first multi-rank all-reduce of the PPO
+    path.  Injected faults in the 2-rank gloo rehearsal: every rank raises / only rank 1 raises while rank 0 sits in the extra's
+    collectives / only rank 0 raises / rank 1 never arrives (watchdog deadline).  Every time: exit code 0, a complete headline line
+    first, and the same line with `failed: ...` in the extra's place last."""
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "20", "--warmup", "5", "--repeats", "1",
+                  "--no-cpu-baseline", "--no-extras",
+                  env_extra={"INVERSUS_BENCH_FAIL_C4": fault, "INVERSUS_BENCH_C4_DEADLINE_S": "45" if fault.startswith("hang") else "300"})
+    res = parse_line(p, with_c4=True)
+    c4 = res["extras"]["C4 selfplay PPO iteration"]
+    assert isinstance(c4, str) and c4.startswith("failed: "), c4
+    assert res["n_gpus"] == 2 and res["value"] > 0 and len(res["roofline"]["kernel_ms_per_rank"]) == 2
+    check_streaming_fields(res)
+    check_gpu_identities(res, 2, shared=True)
 
 
 @pytest.mark.gpu
@@ -117,7 +155,7 @@ def test_rccl_branch_runs_with_one_rank():
     """The nccl (= RCCL) branch -- communicator creation on the GPU, barrier, MAX / SUM all-reduces of the timing -- executed
     for real on the 1-GPU box with a one-rank group (--force-dist)."""
     res = parse_line(run_bench("--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "50", "--warmup", "5", "--repeats", "2",
-                               "--no-cpu-baseline", "--no-extras"))
+                               "--no-cpu-baseline", "--no-extras"), with_c4=True)
     assert res["n_gpus"] == 1 and res["config"]["backend"] == "nccl" and len(res["roofline"]["kernel_ms_per_rank"]) == 1
     check_streaming_fields(res)
     check_gpu_identities(res, 1, shared=False)
@@ -129,7 +167,7 @@ def test_rccl_two_ranks_when_two_gpus_are_visible():
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the driver's multi-GPU node)")
-    res = parse_line(run_bench("--gpus", "2", "--steps", "50", "--warmup", "5", "--repeats", "2", "--no-cpu-baseline", "--no-extras"))
+    res = parse_line(run_bench("--gpus", "2", "--steps", "50", "--warmup", "5", "--repeats", "2", "--no-cpu-baseline", "--no-extras"), with_c4=True)
     assert res["n_gpus"] == 2 and res["config"]["backend"] == "nccl"
     check_gpu_identities(res, 2, shared=False)                         # two ranks on two DISTINCT devices, or bench.py exits
 
