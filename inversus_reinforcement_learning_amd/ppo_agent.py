@@ -208,17 +208,18 @@ class PPOAgent:
             for start in range(0, num_samples, self.batch_size):
                 idx = indices[start:start + self.batch_size]
                 if self.direct_grads:
-                    roctx.push("ppo.minibatch (fused forward + backward + clip/Adam)")
-                    # fused trunk / heads / loss kernels forward and backward without the autograd engine; every gradient is
-                    # written into the flat bucket (nothing to zero), the heads' all-reduce starts before the trunk's backward
-                    means = self.train_fwd.loss_and_grads(obs_grid[idx], obs_extra[idx], actions[idx], old_log_probs[idx], advantages[idx],
-                                                          returns[idx], self.clip_ratio, self.value_coef, self.entropy_coef,
-                                                          after_heads=self.reducer.start_early if self.reducer is not None else None)
-                    if self.reducer is not None:
-                        self.reducer.reduce(average=False)                # SUM over ranks; the 1/world_size rides in the Adam kernel
-                        grad_norm = self.flat_adam.step(grad_scale=1.0 / parallel.world()[1])
-                    else:
-                        grad_norm = self.flat_adam.step()
+                    with roctx.range("ppo.minibatch (fused forward + backward + clip/Adam)"):
+                        # fused trunk / heads / loss kernels forward and backward without the autograd engine; every gradient is
+                        # written into the flat bucket (nothing to zero), the heads' all-reduce starts before the trunk's backward
+                        means = self.train_fwd.loss_and_grads(obs_grid[idx], obs_extra[idx], actions[idx], old_log_probs[idx],
+                                                              advantages[idx], returns[idx], self.clip_ratio, self.value_coef,
+                                                              self.entropy_coef,
+                                                              after_heads=self.reducer.start_early if self.reducer is not None else None)
+                        if self.reducer is not None:
+                            self.reducer.reduce(average=False)            # SUM over ranks; the 1/world_size rides in the Adam kernel
+                            grad_norm = self.flat_adam.step(grad_scale=1.0 / parallel.world()[1])
+                        else:
+                            grad_norm = self.flat_adam.step()
                     policy_loss, value_loss, entropy = means[0], means[1], means[2]
                     if trace:
                         mb_trace.append(torch.stack([policy_loss, value_loss, entropy, grad_norm.detach()]))
@@ -226,7 +227,6 @@ class PPOAgent:
                     tot_v += value_loss
                     tot_e += entropy
                     num_updates += 1
-                    roctx.pop()
                     continue
                 if self.train_fwd is not None:                            # fused trunk kernels; reads packed observations as is
                     logits, values = self.train_fwd(obs_grid[idx], obs_extra[idx])

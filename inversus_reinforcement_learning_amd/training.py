@@ -272,9 +272,13 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=None, help="PPO minibatch size (reference default 512)")
     ap.add_argument("--epochs", type=int, default=None, help="PPO epochs per rollout (reference default 4)")
     ap.add_argument("--lr", type=float, default=None)
+    ap.add_argument("--gae_layout", choices=["per_env", "reference_flat"], default=None,
+                    help="per_env (default): each env's own trajectory; reference_flat: the reference's single chain over the "
+                         "env-interleaved buffer (ppo_agent.py:127-157) -- what its own runs were trained with")
     args = ap.parse_args(argv)
     log_dir = args.log_dir or f"runs/inversus_{args.mode}"
-    kw = {k: v for k, v in (("batch_size", args.batch_size), ("epochs", args.epochs), ("lr", args.lr)) if v is not None}
+    kw = {k: v for k, v in (("batch_size", args.batch_size), ("epochs", args.epochs), ("lr", args.lr), ("gae_layout", args.gae_layout))
+          if v is not None}
     if args.fused:
         kw.update(fused_act=True, fused_update=True)
     if args.mode == "vs_dummy":
