@@ -382,7 +382,10 @@ typedef struct { float *db1, *dwe, *db2[2], *dw3[2], *db3[2]; } inv_heads_grads;
 int  inv_heads_bwd(const inv_heads_params *params, const float *dlogits, const float *dvalue, const void *h, const void *a2,
                    const float *extra, void *dpre_bf16, void *dpre_t_bf16, int32_t dpre_t_ld, void *da2_bf16, const inv_heads_grads *grads,
                    int32_t B, void *stream);
-/* dW2[h] f32 [128][256] += da2[:, 128 h : 128 h + 128]^T h_saved[:, 256 h : 256 h + 256] (zero the two buffers first). */
+/* dW2[h] f32 [128][256] += da2[:, 128 h : 128 h + 128]^T h_saved[:, 256 h : 256 h + 256] (zero the two buffers first).
+ * Determinism: the partial sums of the 256-sample chunks (B / 256 per head) are ADDED with f32 atomics, like db1 / dwe / db2 / dw3 / db3
+ * of inv_heads_bwd: these gradients are equal between launches to f32 reassociation (~1e-7 relative), NOT bit for bit -- unlike
+ * inv_fc1_fwd / _dfeat / _dw (fixed-order slab sums, no atomics) and unlike the torch.bmm + sum(0) form this kernel replaced. */
 int  inv_heads_dw2(const void *da2_bf16, const void *h_bf16, int32_t B, float *dw2_actor, float *dw2_critic, void *stream);
 
 /* ---- the scalar tail of the PPO update ------------------------------------------------------

@@ -123,6 +123,65 @@ __device__ __forceinline__ float wave_sum(float x)
     return (r0 + r1) + (r2 + r3);
 }
 
+
+// ---- GEMM core of the 10 x 15 kernels (round 5): input rows SHARED across the three vertical taps ---------------------------
+// The B fragment of output row i for tap (dy, dx) is input row i + dy (haloed coordinates) shifted by dx: the same 16 positions x
+// 32 channels that output row i + 1 needs for tap (dy - 1, dx).  A wave owns whole board rows, so it reads every input row
+// fragment ONCE per (channel group, dx) and feeds it to the (up to) three output rows it belongs to, each with that tap row's own
+// weight fragment:
+//     for (kc, dx):  A[dy][mi] = W fragments of taps (0..2, dx), channel group kc            (3 * MW loads, one group ahead)
+//                    for input row jq:  B = tile[row jq][.. + dx][kc]                         (ONE ds_read_b128)
+//                                       acc[mi][jq - dy] += A[dy][mi] * B   for dy = 0, 1, 2   (up to 3 * MW MFMAs)
+// instead of one read per (output row, tap, kc): 10 instead of 30 fragment reads per (kc, dx) for a wave that owns all ten rows
+// (1 440 -> 480 KB of LDS reads per sample in conv4), one address register instead of NW.  FULL (the wave owns rows 0 .. H-1):
+// the top and bottom halo rows are all zeros and are skipped -- 28 instead of 30 MFMAs per (kc, dx, mi), -6.7 % matrix work.
+// k-order of every accumulator: (kc, dx, dy) -- the training forward, the rollout forward with its numerics and the backward's
+// transposed convolutions all run THIS loop (bit-identical features between the first two is a tested property).
+template <int CIN, int MW, int NW, bool FULL>
+__device__ __forceinline__ void conv_gemm_rows(const void *w, const bf16 *tile, int lane, int m0, int n0, f32x4 (&acc)[MW][NW])
+{
+    constexpr int KPT = CIN / 32, KS = 9 * KPT, NG = 3 * KPT;
+    constexpr int JQ0 = FULL ? 1 : 0, NR = FULL ? NW : NW + 2;       // input rows jq = JQ0 .. JQ0 + NR - 1 (relative to haloed row n0)
+    constexpr int NS = NG * NR;                                      // row steps of the whole GEMM
+    constexpr int BD = 3;                                            // B fragments are requested BD - 1 row steps ahead
+    const int c16 = lane & 15, kg = lane >> 4;
+    const bf16 *rp = tile + (n0 * PW + c16) * CSF + 8 * kg;          // every fragment address = rp + an immediate
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(w) + (size_t)m0 * KS * 64 + lane;
+    bf16x8 a[2][3][MW], b[BD];
+#define POL_ROWS_A(g, slot)                                                                                        \
+    _Pragma("unroll") for (int dy_ = 0; dy_ < 3; ++dy_)                                                            \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < MW; ++mi_)                                                       \
+            a[slot][dy_][mi_] = wp[((size_t)mi_ * KS + (dy_ * 3 + (g) % 3) * KPT + (g) / 3) * 64]
+#define POL_ROWS_B(t) (*reinterpret_cast<const bf16x8 *>(rp + ((JQ0 + (t) % NR) * PW + ((t) / NR) % 3) * CSF + (((t) / NR) / 3) * 32))
+    POL_ROWS_A(0, 0);
+#pragma unroll
+    for (int t = 0; t < BD - 1; ++t) b[t] = POL_ROWS_B(t < NS ? t : NS - 1);
+    // two nested fully unrolled loops (one flat loop of NS steps exceeds the unroller's size budget for pragma loops and is left
+    // rolled, with the fragment arrays in scratch): every index below is a constant after unrolling
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) { POL_ROWS_A(g + 1, (g + 1) & 1); }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = g * NR + r, jq = JQ0 + r;
+            if (t + BD - 1 < NS) b[(t + BD - 1) % BD] = POL_ROWS_B(t + BD - 1);
+            POL_PIN();
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int i = jq - dy;                               // output row (relative to n0) this input row serves through tap row dy
+                if (i >= 0 && i < NW) {
+#pragma unroll
+                    for (int mi = 0; mi < MW; ++mi)
+                        acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g & 1][dy][mi], b[t % BD], acc[mi][i], 0, 0, 0);
+                }
+            }
+            POL_PIN();
+        }
+    }
+#undef POL_ROWS_A
+#undef POL_ROWS_B
+}
+
 // One conv3x3 (pad 1) + bias (+ residual) + LayerNorm over the whole sample + ReLU, as an implicit GEMM on
 // v_mfma_f32_16x16x32_bf16:  D[cout][pixel] += W[cout][k] . X[k][pixel],  k-step = (tap, 32 channels).
 //   A fragment (weights, global, pre-packed):  lane l holds W[16*mt + (l&15)][32*ks + 8*(l>>4) + j]
@@ -147,15 +206,13 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     // bit for some samples and ~4e-7 of the features by one bf16 ulp -- the training forward and the rollout forward with
     // its numerics (TN) must agree bit for bit.
 #pragma clang fp contract(off)
-    constexpr int KPT = CIN / 32, KS = 9 * KPT;
     const int c16 = lane & 15, kg = lane >> 4;
 
-    int pix[NW], base[NW], tap0[NW];
+    int pix[NW], base[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         pix[i] = (n0 + i) * W + min(c16, W - 1);                    // tile = board row n0 + i; column 15 is a dummy (never stored)
         base[i] = ((n0 + i + 1) * PW + c16 + 1) * CSF;              // the dummy column sits on the right halo: reads zeros
-        tap0[i] = base[i] - (PW + 1) * CSF + 8 * kg;                // fragment address of tap (0,0), channel group 0
     }
 
     // the accumulators start at the conv bias (4 consecutive channels per lane: one 16-B load per row block, requested
@@ -168,39 +225,7 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         for (int i = 0; i < NW; ++i) { acc[mi][i][0] = bq.x; acc[mi][i][1] = bq.y; acc[mi][i][2] = bq.z; acc[mi][i][3] = bq.w; }
     }
 
-    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
-    constexpr int AD = 3;                                            // weight fragments are requested AD k-steps ahead (L2 latency; 2 and 4 measured equal)
-    bf16x8 a[AD + 1][MW], b[NW];
-#pragma unroll
-    for (int d = 0; d < AD; ++d)
-#pragma unroll
-        for (int mi = 0; mi < MW; ++mi) a[d][mi] = wp[((size_t)mi * KS + (d < KS ? d : KS - 1)) * 64];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i]);
-    // fully unrolled: every tap / channel-group offset is an immediate of the ds_read / global_load.
-    // Software pipeline in place: the weight fragments of k-step s+AD are requested at the top of k-step s
-    // (ring of AD+1 register sets), and each activation fragment is re-loaded for k-step s+1 right after its
-    // last MFMA of k-step s (one k-step = MW*NW MFMAs of latency cover, no second fragment buffer).
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int ksn = ks + 1 < KS ? ks + 1 : ks;                 // redundant prefetches at the end stay in bounds
-        const int ksa = ks + AD < KS ? ks + AD : KS - 1;
-        const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
-        const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSF + kcn * 32;
-#pragma unroll
-        for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
-        POL_PIN();
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            {
-#pragma unroll
-                for (int mi = 0; mi < MW; ++mi)
-                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
-            }
-            b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
-            POL_PIN();
-        }
-    }
+    conv_gemm_rows<CIN, MW, NW, NW == H>(lp.w, tile, lane, m0, n0, acc);
 
     STAMP(1 + layer);                                                // GEMM
     // LayerNorm affine parameters of ALL this wave's tiles are requested now -- fp16 [pixel][COUT/4][8] = {weight x4, bias x4}
@@ -582,20 +607,72 @@ __device__ __forceinline__ void band_load_obs(bf16 *tile, const uint32_t *obw, c
     }
 }
 
+
+// The banded kernels' GEMM core with the input rows shared across the vertical taps (see conv_gemm_rows): a wave owns RW = NW / TPR
+// whole rows of the band (TPR 16-pixel tiles per row), reads each of the RW + 2 input rows once per (channel group, dx, row half)
+// and feeds it to the up to three output rows it belongs to.  Every row of a band tile can hold data (the halo rows are the
+// neighbouring bands' rows), so no row is skipped.
+template <class G, int CIN, int MW, int NW>
+__device__ __forceinline__ void band_gemm_rows(const void *w, const bf16 *tile, int lane, int m0, int n0, f32x4 (&acc)[MW][NW])
+{
+    constexpr int KPT = CIN / 32, KS = 9 * KPT, NG = 3 * KPT, TPR = G::TPR, RW = NW / TPR;
+    static_assert(NW % TPR == 0, "a wave owns whole rows of the band");
+    constexpr int NR = (RW + 2) * TPR, NS = NG * NR, BD = 3;
+    const int c16 = lane & 15, kg = lane >> 4;
+    const bf16 *rp = tile + ((n0 / TPR) * G::PWB + c16) * CSF + 8 * kg;
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(w) + (size_t)m0 * KS * 64 + lane;
+    bf16x8 a[2][3][MW], b[BD];
+#define POL_ROWS_A(g, slot)                                                                                        \
+    _Pragma("unroll") for (int dy_ = 0; dy_ < 3; ++dy_)                                                            \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < MW; ++mi_)                                                       \
+            a[slot][dy_][mi_] = wp[((size_t)mi_ * KS + (dy_ * 3 + (g) % 3) * KPT + (g) / 3) * 64]
+#define POL_ROWS_B(t) (*reinterpret_cast<const bf16x8 *>(rp + ((((t) % NR) / TPR) * G::PWB + (((t) % NR) % TPR) * 16 + ((t) / NR) % 3) * CSF + (((t) / NR) / 3) * 32))
+    POL_ROWS_A(0, 0);
+#pragma unroll
+    for (int t = 0; t < BD - 1; ++t) b[t] = POL_ROWS_B(t < NS ? t : NS - 1);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if ((!(POL_BAND_KNOCK & 2)) && g + 1 < NG) { POL_ROWS_A(g + 1, (g + 1) & 1); }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = g * NR + r, jq = r / TPR, h = r % TPR;
+            if (!(POL_BAND_KNOCK & 16) && t + BD - 1 < NS) b[(t + BD - 1) % BD] = POL_ROWS_B(t + BD - 1);
+            POL_PIN();
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int ro = jq - dy;
+                if (ro >= 0 && ro < RW) {
+#pragma unroll
+                    for (int mi = 0; mi < MW; ++mi) {
+                        if (POL_BAND_KNOCK & 1) {
+                            typedef unsigned int knock_u4 __attribute__((ext_vector_type(4)));
+                            asm volatile("" :: "v"(__builtin_bit_cast(knock_u4, a[(POL_BAND_KNOCK & 2) ? 0 : (g & 1)][dy][mi])), "v"(__builtin_bit_cast(knock_u4, b[t % BD])));
+                        } else {
+                            acc[mi][ro * TPR + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(POL_BAND_KNOCK & 2) ? 0 : (g & 1)][dy][mi], b[t % BD],
+                                                                                           acc[mi][ro * TPR + h], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            POL_PIN();
+        }
+    }
+#undef POL_ROWS_A
+#undef POL_ROWS_B
+}
+
 // conv3x3 on the band + bias (+ residual), statistics, z (bf16) back to the scratch through the tile
 template <class G, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL>
 __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile, bf16 *__restrict__ zout, int band, int lane, int m0, int n0, float &s, float &ss,
                                           unsigned long long &stamp_prev, int slot0 = 0)
 {
-    constexpr int KPT = CIN / 32, KS = 9 * KPT;
     asm volatile("" : "+v"(lane));
     const int c16 = lane & 15, kg = lane >> 4;
-    int base[NW], tap0[NW];
+    int base[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int t = n0 + i, rr = t / G::TPR, col0 = (t - rr * G::TPR) * 16;
         base[i] = ((rr + 1) * G::PWB + col0 + c16 + 1) * CSF;
-        tap0[i] = base[i] - (G::PWB + 1) * CSF + 8 * kg;
     }
     f32x4 acc[MW][NW];
 #pragma unroll
@@ -604,41 +681,7 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
 #pragma unroll
         for (int i = 0; i < NW; ++i) { acc[mi][i][0] = bq.x; acc[mi][i][1] = bq.y; acc[mi][i][2] = bq.z; acc[mi][i][3] = bq.w; }
     }
-    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(lp.w) + (size_t)m0 * KS * 64 + lane;
-    constexpr int AD = 3;
-    bf16x8 a[AD + 1][MW], b[NW];
-#pragma unroll
-    for (int d = 0; d < AD; ++d)
-#pragma unroll
-        for (int mi = 0; mi < MW; ++mi) a[d][mi] = wp[((size_t)mi * KS + (d < KS ? d : KS - 1)) * 64];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int ksn = ks + 1 < KS ? ks + 1 : ks;
-        const int ksa = ks + AD < KS ? ks + AD : KS - 1;
-        const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
-        const int off_n = ((tapn / 3) * G::PWB + (tapn % 3)) * CSF + kcn * 32;
-        if (!(POL_BAND_KNOCK & 2) || ks == 0) {
-#pragma unroll
-            for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
-        }
-        POL_PIN();
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-#pragma unroll
-            for (int mi = 0; mi < MW; ++mi) {
-                if (POL_BAND_KNOCK & 1) {
-                    typedef unsigned int knock_u4 __attribute__((ext_vector_type(4)));
-                    asm volatile("" :: "v"(__builtin_bit_cast(knock_u4, a[ks % (AD + 1)][mi])), "v"(__builtin_bit_cast(knock_u4, b[i])));
-                } else {
-                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
-                }
-            }
-            if (!(POL_BAND_KNOCK & 16)) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
-            POL_PIN();
-        }
-    }
+    band_gemm_rows<G, CIN, MW, NW>(lp.w, tile, lane, m0, n0, acc);
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
         const int ch0 = (m0 + mi) * 16 + 4 * kg;
@@ -825,54 +868,13 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
 template <int CIN, int COUT, int MW, int NW>
 __device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int lane, int m0, int n0, f32x4 (&acc)[MW][NW])
 {
-    constexpr int KPT = CIN / 32, KS = 9 * KPT;
-    const int c16 = lane & 15, kg = lane >> 4;
-    int tap0[NW];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        tap0[i] = ((n0 + i + 1) * PW + c16 + 1) * CSF - (PW + 1) * CSF + 8 * kg;       // tile = board row, column 15 = right halo (zeros)
-    }
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
         for (int i = 0; i < NW; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
-    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(w) + (size_t)m0 * KS * 64 + lane;
-    constexpr int AD = 3;
-    bf16x8 a[AD + 1][MW], b[NW];
-#pragma unroll
-    for (int d = 0; d < AD; ++d)
-#pragma unroll
-        for (int mi = 0; mi < MW; ++mi) a[d][mi] = wp[((size_t)mi * KS + (d < KS ? d : KS - 1)) * 64];
-#pragma unroll
-    for (int i = 0; i < NW; ++i) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int ksn = ks + 1 < KS ? ks + 1 : ks;
-        const int ksa = ks + AD < KS ? ks + AD : KS - 1;
-        const int tapn = ksn / KPT, kcn = ksn - tapn * KPT;
-        const int off_n = ((tapn / 3) * PW + (tapn % 3)) * CSF + kcn * 32;
-        if (!(POL_BAND_KNOCK & 2) || ks == 0) {
-#pragma unroll
-            for (int mi = 0; mi < MW; ++mi) a[(ks + AD) % (AD + 1)][mi] = wp[((size_t)mi * KS + ksa) * 64];
-        }
-        POL_PIN();
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-#pragma unroll
-            for (int mi = 0; mi < MW; ++mi) {
-                if (POL_BAND_KNOCK & 1) {
-                    typedef unsigned int knock_u4 __attribute__((ext_vector_type(4)));
-                    asm volatile("" :: "v"(__builtin_bit_cast(knock_u4, a[ks % (AD + 1)][mi])), "v"(__builtin_bit_cast(knock_u4, b[i])));
-                } else {
-                    acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks % (AD + 1)][mi], b[i], acc[mi][i], 0, 0, 0);
-                }
-            }
-            if (!(POL_BAND_KNOCK & 16)) b[i] = *reinterpret_cast<const bf16x8 *>(tile + tap0[i] + off_n);
-            POL_PIN();
-        }
-    }
+    conv_gemm_rows<CIN, MW, NW, NW == H>(w, tile, lane, m0, n0, acc);
 }
 
 // The LayerNorm / ReLU backward does not need the accumulator layout: da goes through the LDS tile as bf16 and ALL 256

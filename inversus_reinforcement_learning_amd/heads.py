@@ -9,7 +9,13 @@ The backward's two big products (d features, d W1) are inv_fc1_dfeat / inv_fc1_d
 `HeadsOperands` packs a policy's head parameters for the kernels (rollouts: once per refresh); `heads_train` is the differentiable
 form the fused PPO update uses (packs per call -- the parameters change every minibatch -- and returns gradients for all 12 head
 tensors and for the features).  Only the reference's head sizes (hidden_dim = 256) have kernels; callers keep their torch tail for
-anything else."""
+anything else.
+
+Batch size and summation order: inv_fc1_fwd splits K into inv_fc1_fwd_slabs(B, nout, K) slabs (a function of B and the CU count: 2 at
+B = 16 384, up to 8 for small minibatches on 256 CUs), summed in slab order -- so a sample's `pre` is bit-identical between launches of
+ONE batch size and equal to f32 reassociation between DIFFERENT ones: |d logits| < 2e-3 max, < 2e-5 mean at 16 384 vs 512 rows
+(tests/test_gpu_heads.py).  PPO's epoch-0 ratio is therefore exactly 1 when minibatch = rollout batch (the 16 384-env configurations)
+and 1 +- 2e-3 otherwise; results on GPUs with another CU count differ by the same reassociation."""
 import ctypes as C
 
 import torch
@@ -28,9 +34,10 @@ def _stream():
 
 
 def supported(policy):
+    """The reference's head sizes AND an even pixel count: inv_fc1_dfeat / inv_fc1_dw tile the 128 P feature columns in 256s."""
     a, c = policy.fc_actor, policy.fc_critic
     return (a[0].out_features == HID and a[2].out_features == MID and a[4].out_features == NACT and c[0].out_features == HID
-            and c[2].out_features == MID and c[4].out_features == 1)
+            and c[2].out_features == MID and c[4].out_features == 1 and (a[0].in_features - 4) % 256 == 0)
 
 
 def _pack_fc1(weights, pixels):
@@ -157,6 +164,9 @@ class _HeadsTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, extra, *tensors):
         pixels = feat.shape[1] // 128
+        if feat.shape[1] != 128 * pixels or pixels % 2:
+            raise ValueError(f"heads_train: the backward kernels (inv_fc1_dfeat / inv_fc1_dw) need an even pixel count, got "
+                             f"{feat.shape[1]} features = 128 x {feat.shape[1] / 128:g} pixels")
         ops = HeadsOperands([tensors[:6], tensors[6:]], pixels, need_t=True)
         logits, value, extra_c, h, a2 = ops.forward(feat, extra, save=True)
         ctx.ops = ops

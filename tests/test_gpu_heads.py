@@ -104,6 +104,47 @@ def test_actor_only_equals_the_actor_of_both_heads_and_results_do_not_depend_on_
         assert torch.equal(lo, l2[sub]) and torch.equal(va, v2[sub])
 
 
+def test_act_and_update_batch_sizes_split_k_differently_and_the_logits_differ_by_f32_reassociation_only():
+    """Advisor r4: the forward's split-K count comes from inv_fc1_fwd_slabs(B, nout, K) (B and the CU count), so the stored
+    old_log_prob of a 16 384-row rollout forward (2 slabs here) and the update's recomputation on a smaller minibatch (up to 8 slabs)
+    add the same f32 products in another order.  The documented tolerance (heads.py): logits / values equal to f32 reassociation --
+    max |d| < 2e-3 on logits of O(1) ... O(10), mean |d| < 2e-5 -- so the PPO ratio of epoch 0 is 1 +- 2e-3 when the minibatch is
+    smaller than the rollout batch, and exactly 1 when they are equal (test_gpu_fused_train)."""
+    import torch
+    from inversus_reinforcement_learning_amd import heads as HD, _lib as L
+    lib = L.load()
+    pol = _policy(3)
+    B, mb = 16384, 512
+    feat, extra = _inputs(B, 3)
+    s_roll, s_mb = int(lib.inv_fc1_fwd_slabs(B, 512, 19200)), int(lib.inv_fc1_fwd_slabs(mb, 512, 19200))
+    assert s_roll >= 1 and s_mb >= 1 and s_roll != s_mb                     # the case the finding is about (otherwise the test proves nothing)
+    ops = HD.HeadsOperands(HD.head_tensors(pol), 150)
+    with torch.no_grad():
+        lo, va = ops.forward(feat, extra)
+        dl, dv = [], []
+        for k in range(0, B, 4096):                                         # a sample of minibatches out of the rollout batch
+            lo_m, va_m = ops.forward(feat[k:k + mb].contiguous(), extra[k:k + mb].contiguous())
+            dl.append((lo_m - lo[k:k + mb]).abs()); dv.append((va_m - va[k:k + mb]).abs())
+        dl, dv = torch.cat(dl), torch.cat(dv)
+        assert float(dl.max()) < 2e-3 and float(dv.max()) < 2e-3 and float(dl.mean()) < 2e-5 and float(dv.mean()) < 2e-5
+        lo2, va2 = ops.forward(feat, extra)                                 # equal sizes: the same bits (no atomics anywhere on this path)
+        assert torch.equal(lo2, lo) and torch.equal(va2, va)
+
+
+def test_an_odd_pixel_count_is_refused_before_the_forward_runs():
+    """Advisor r4: inv_fc1_dfeat / inv_fc1_dw need 128 P to be a multiple of 256 (an even pixel count); heads_train has no torch tail,
+    so an odd-P board must fail BEFORE the forward, not with INV_ERR_BAD_ARG in the middle of backward."""
+    import torch
+    from inversus_reinforcement_learning_amd import heads as HD
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    pol = InversusCNNPolicy(12, 3, 5, 4).cuda()                             # 15 pixels: odd
+    assert not HD.supported(pol)
+    feat = torch.zeros((4, 128 * 15), dtype=torch.bfloat16, device="cuda", requires_grad=False)
+    with pytest.raises(ValueError, match="even"):
+        HD.heads_train(pol, feat, torch.zeros((4, 4), device="cuda"))
+    assert HD.supported(InversusCNNPolicy(12, 4, 5, 4).cuda()) and HD.supported(_policy())
+
+
 @pytest.mark.parametrize("n", [33, 1024])
 def test_gradients_match_f32_autograd(n):
     import torch
