@@ -588,14 +588,10 @@ static int fc1_status(const char *what)
 template <int MODE>
 static int fc1_launch(const fc1::Args &a, int grid, hipStream_t st, const char *what)
 {
-    static bool attr_done[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (!attr_done[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
-        if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "%s: hipFuncSetAttribute(%d B of LDS): %s", what, fc1::LDS_BYTES, hipGetErrorString(e));
-        attr_done[dev] = true;
-    }
+    // per launch: a cheap host call, and correct on every device ordinal and from every host thread (a cached "done" flag per device
+    // would be a data race between threads and wrong past its table size)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc1::k_fc1_gemm<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, fc1::LDS_BYTES);
+    if (e != hipSuccess) return inv_fail(INV_ERR_HIP, "%s: hipFuncSetAttribute(%d B of LDS): %s", what, fc1::LDS_BYTES, hipGetErrorString(e));
     hipLaunchKernelGGL((fc1::k_fc1_gemm<MODE>), dim3(grid), dim3(fc1::THREADS), fc1::LDS_BYTES, st, a);
     return fc1_status(what);
 }

@@ -88,6 +88,11 @@ __device__ __forceinline__ int pos_of(int p) { return (p / W + 1) * PW + (p % W)
 // accumulated into a buffer of its own that no kernel code reads (cdna_hip_programming.md, "In-kernel stamps").
 #ifdef INV_POLICY_STAMPS
 __device__ unsigned long long g_stamps[4 * 32];          // [wave][slot]
+// Round 5: the deltas are accumulated in LDS (ds_add_u64, no return: counted in lgkmcnt, a few cycles) and flushed to g_stamps once
+// per workgroup at the end of the kernel.  The first version did a GLOBAL atomic per stamp: every later `s_waitcnt vmcnt` of the
+// kernel (LayerNorm parameters, weight fragments) then also waited for that atomic (vmcnt retires in order), which inflated the
+// epilogue segments by the atomic's round trip and doubled the stamped build's run time.
+__shared__ unsigned long long s_stamps[4 * 32];
 __device__ __forceinline__ unsigned long long stamp_now()
 {
     unsigned long long t;
@@ -99,11 +104,15 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define STAMP(slot)                                                                          \
     do {                                                                                     \
         const unsigned long long now_ = stamp_now();                                         \
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[(threadIdx.x >> 6) * 32 + (slot)], now_ - stamp_prev); \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_stamps[(threadIdx.x >> 6) * 32 + (slot)], now_ - stamp_prev); \
         stamp_prev = now_;                                                                   \
     } while (0)
+#define STAMP_INIT() do { if (threadIdx.x < 128) s_stamps[threadIdx.x] = 0ull; __syncthreads(); } while (0)
+#define STAMP_FLUSH() do { __syncthreads(); if (threadIdx.x < 128) atomicAdd(&g_stamps[threadIdx.x], s_stamps[threadIdx.x]); } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define STAMP_INIT() do { } while (0)
+#define STAMP_FLUSH() do { } while (0)
 #endif
 
 // Sum over the 64 lanes, result in every lane.  Rows of 16 lanes reduce with four DPP adds (quad swaps, half-row and row
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
     __syncthreads();
 
     unsigned long long stamp_prev = 0;
+    STAMP_INIT();
 #ifdef INV_POLICY_STAMPS
     stamp_prev = stamp_now();
 #endif
@@ -491,6 +501,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
         __syncthreads();
         STAMP(13);                                                   // feature write-out
     }
+    STAMP_FLUSH();
 }
 
 
@@ -762,6 +773,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
     }
     __syncthreads();
+    STAMP_INIT();
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         int lane_i = lane;
         asm volatile("" : "+v"(lane_i));
@@ -852,6 +864,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         __syncthreads();                                             // zB / obw are rewritten by the next sample
         STAMP(16);                                                   // statistics + feature pass
     }
+    STAMP_FLUSH();
 }
 
 
