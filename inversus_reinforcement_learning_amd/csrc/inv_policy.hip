@@ -146,30 +146,40 @@ __device__ __forceinline__ float wave_sum(float x)
 // the top and bottom halo rows are all zeros and are skipped -- 28 instead of 30 MFMAs per (kc, dx, mi), -6.7 % matrix work.
 // k-order of every accumulator: (kc, dx, dy) -- the training forward, the rollout forward with its numerics and the backward's
 // transposed convolutions all run THIS loop (bit-identical features between the first two is a tested property).
-template <int CIN, int MW, int NW, bool FULL>
-__device__ __forceinline__ void conv_gemm_rows(const void *w, const bf16 *tile, int lane, int m0, int n0, f32x4 (&acc)[MW][NW])
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `early`: called once, at the start of the LAST (kc, dx) group (after every weight fragment has been requested): the caller's loads that
+// should be in flight while the last 28 x MW MFMAs run (the LayerNorm parameters of the forward's epilogue).
+// A layer with ONE channel group (CIN = 32: three groups of 15-28 MFMAs, each far shorter than an L2 round trip) requests all its nine
+// fragments up front; the wide layers keep a ring of two groups.  (Measured and not kept, profiles/r05_trunk_experiments.md: the first
+// group's fragments and the bias requested by the CALLER across the previous layer's statistics / barriers / epilogue -- 24 more live
+// registers, no gain, as in round 2.)
+template <int CIN, int MW, int NW, bool FULL, class HOOK = NoHook>
+__device__ __forceinline__ void conv_gemm_rows(const void *w, const bf16 *tile, int lane, int m0, int n0, f32x4 (&acc)[MW][NW], const HOOK &early = HOOK())
 {
     constexpr int KPT = CIN / 32, KS = 9 * KPT, NG = 3 * KPT;
     constexpr int JQ0 = FULL ? 1 : 0, NR = FULL ? NW : NW + 2;       // input rows jq = JQ0 .. JQ0 + NR - 1 (relative to haloed row n0)
     constexpr int NS = NG * NR;                                      // row steps of the whole GEMM
     constexpr int BD = 3;                                            // B fragments are requested BD - 1 row steps ahead
+    constexpr int NSLOT = NG <= 3 ? NG : 2, PG = NG <= 3 ? NG : 1;   // one channel group: every fragment resident; else a ring of two groups
     const int c16 = lane & 15, kg = lane >> 4;
     const bf16 *rp = tile + (n0 * PW + c16) * CSF + 8 * kg;          // every fragment address = rp + an immediate
     const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(w) + (size_t)m0 * KS * 64 + lane;
-    bf16x8 a[2][3][MW], b[BD];
+    bf16x8 a[NSLOT][3][MW], b[BD];
 #define POL_ROWS_A(g, slot)                                                                                        \
     _Pragma("unroll") for (int dy_ = 0; dy_ < 3; ++dy_)                                                            \
         _Pragma("unroll") for (int mi_ = 0; mi_ < MW; ++mi_)                                                       \
             a[slot][dy_][mi_] = wp[((size_t)mi_ * KS + (dy_ * 3 + (g) % 3) * KPT + (g) / 3) * 64]
 #define POL_ROWS_B(t) (*reinterpret_cast<const bf16x8 *>(rp + ((JQ0 + (t) % NR) * PW + ((t) / NR) % 3) * CSF + (((t) / NR) / 3) * 32))
-    POL_ROWS_A(0, 0);
+#pragma unroll
+    for (int g = 0; g < PG; ++g) { POL_ROWS_A(g, g); }
 #pragma unroll
     for (int t = 0; t < BD - 1; ++t) b[t] = POL_ROWS_B(t < NS ? t : NS - 1);
     // two nested fully unrolled loops (one flat loop of NS steps exceeds the unroller's size budget for pragma loops and is left
     // rolled, with the fragment arrays in scratch): every index below is a constant after unrolling
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) { POL_ROWS_A(g + 1, (g + 1) & 1); }
+        if (NG > 3 && g + 1 < NG) { POL_ROWS_A(g + 1, (g + 1) & 1); }
+        if (g == NG - 1) { early(); POL_PIN(); }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int t = g * NR + r, jq = JQ0 + r;
@@ -181,7 +191,7 @@ __device__ __forceinline__ void conv_gemm_rows(const void *w, const bf16 *tile, 
                 if (i >= 0 && i < NW) {
 #pragma unroll
                     for (int mi = 0; mi < MW; ++mi)
-                        acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g & 1][dy][mi], b[t % BD], acc[mi][i], 0, 0, 0);
+                        acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g % NSLOT][dy][mi], b[t % BD], acc[mi][i], 0, 0, 0);
                 }
             }
             POL_PIN();
@@ -234,24 +244,40 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         for (int i = 0; i < NW; ++i) { acc[mi][i][0] = bq.x; acc[mi][i][1] = bq.y; acc[mi][i][2] = bq.z; acc[mi][i][3] = bq.w; }
     }
 
-    conv_gemm_rows<CIN, MW, NW, NW == H>(lp.w, tile, lane, m0, n0, acc);
-
-    STAMP(1 + layer);                                                // GEMM
-    // LayerNorm affine parameters of ALL this wave's tiles are requested now -- fp16 [pixel][COUT/4][8] = {weight x4, bias x4}
-    // of 4 consecutive channels, ONE 16-byte load per tile -- so that their L2 round trip overlaps the statistics and the
-    // barrier (the weight / activation fragment registers of the GEMM are dead here).  Requested group by group inside the
-    // epilogue they cost 15 % of the kernel (a build without them: 1.08 vs 1.27 ms; profiles/r02_trunk_knockouts.md).
-    f16x8 ln[SAVE ? 1 : MW][SAVE ? 1 : NW];
-    if constexpr (!SAVE) {
+    // residual (layer 4): this lane's own input elements are added to the accumulators' START values (bias + residual) BEFORE the GEMM
+    // -- its inputs do not change, the LDS round trips hide behind the first MFMAs, and nothing but the statistics is left between the
+    // GEMM and the statistics barrier (read after the GEMM they were ten dependent read -> wait -> add groups on the wave's critical
+    // path: "bias+stats L4" = 9.3 % of a sample in profiles/r05_v2_policy_stamps_lds.json)
+    if constexpr (RESIDUAL) {
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                ln[mi][i] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(lp.ln) +
-                                                             ((size_t)min(pix[i], P - 1) * COUT + (m0 + mi) * 16 + 4 * kg) * 2);
+                const bf16x4 r4 = *reinterpret_cast<const bf16x4 *>(tile + base[i] + (m0 + mi) * 16 + 4 * kg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mi][i][e] += (float)r4[e];
             }
-        POL_PIN();
     }
+    // LayerNorm affine parameters of ALL this wave's tiles -- fp16 [pixel][COUT/4][8] = {weight x4, bias x4} of 4 consecutive channels,
+    // ONE 16-byte load per tile -- are requested early enough for their L2 round trip to overlap the statistics and the barrier (the
+    // weight / activation fragment registers of the GEMM are dead there).  Requested group by group inside the epilogue they cost 15 %
+    // of the kernel (a build without them: 1.08 vs 1.27 ms; profiles/r02_trunk_knockouts.md).  Round 5: requested at the start of the
+    // GEMM's LAST (kc, dx) group (conv_gemm_rows' `early` hook) instead of after it: their round trip also hides behind the last
+    // 28 x MW MFMAs, -2.5 % per forward (profiles/r05_trunk_experiments.md).
+    f16x8 ln[SAVE ? 1 : MW][SAVE ? 1 : NW];
+    auto load_ln = [&]() {
+        if constexpr (!SAVE) {
+#pragma unroll
+            for (int mi = 0; mi < MW; ++mi)
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    ln[mi][i] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(lp.ln) +
+                                                                 ((size_t)min(pix[i], P - 1) * COUT + (m0 + mi) * 16 + 4 * kg) * 2);
+                }
+        }
+    };
+    conv_gemm_rows<CIN, MW, NW, NW == H>(lp.w, tile, lane, m0, n0, acc, load_ln);
+    STAMP(1 + layer);                                                // GEMM
     // (+ residual) and the LayerNorm statistics
     static_assert(!RAGGED, "tile ownership is 5 or 10 full-width tiles per wave");
     (void)ncount;
@@ -259,30 +285,27 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     float s, ss;
     // the sums run on accumulator PAIRS with v_pk_add_f32 / v_pk_fma_f32 (4 instructions per quad instead of 10; VALU issue,
     // not LDS or latency, is what the knock-out probes show to be scarce).  Every instantiation sums in the same order.
+    // Four INDEPENDENT chains (sum / sum of squares x the two register pairs of a quad): a dependent vector instruction beside the
+    // co-resident workgroup's MFMA stream issues once per MFMA slot, so one chain of 4 x MW x NW dependent packed adds was ~1 000 cycles
+    // of this segment by itself.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 s2 = { 0.0f, 0.0f }, ss2 = { 0.0f, 0.0f };
+    f32x2 sA = { 0.0f, 0.0f }, sB = { 0.0f, 0.0f }, qA = { 0.0f, 0.0f }, qB = { 0.0f, 0.0f };
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi) {
-        const int ch0 = (m0 + mi) * 16 + 4 * kg;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            float x0 = acc[mi][i][0], x1 = acc[mi][i][1], x2 = acc[mi][i][2], x3 = acc[mi][i][3];
-            if (RESIDUAL) {
-                const bf16x4 rq = *reinterpret_cast<const bf16x4 *>(tile + base[i] + ch0);
-                x0 += (float)rq[0]; x1 += (float)rq[1]; x2 += (float)rq[2]; x3 += (float)rq[3];
-                acc[mi][i][0] = x0; acc[mi][i][1] = x1; acc[mi][i][2] = x2; acc[mi][i][3] = x3;
-            }
+            const float x0 = acc[mi][i][0], x1 = acc[mi][i][1], x2 = acc[mi][i][2], x3 = acc[mi][i][3];
             {
                 const f32x2 pa = { x0, x1 }, pb = { x2, x3 };
-                s2 += pa;
-                s2 += pb;
-                ss2 = __builtin_elementwise_fma(pa, pa, ss2);
-                ss2 = __builtin_elementwise_fma(pb, pb, ss2);
+                sA += pa;
+                sB += pb;
+                qA = __builtin_elementwise_fma(pa, pa, qA);
+                qB = __builtin_elementwise_fma(pb, pb, qB);
             }
         }
     }
-    s = s2[0] + s2[1];
-    ss = ss2[0] + ss2[1];
+    s = (sA[0] + sA[1]) + (sB[0] + sB[1]);
+    ss = (qA[0] + qA[1]) + (qB[0] + qB[1]);
     if (!vcol) { s = 0.0f; ss = 0.0f; }                              // row tiles: the dummy column's sums
     s = wave_sum(s);
     ss = wave_sum(ss);
@@ -291,13 +314,14 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
     STAMP(14 + layer);                                               // bias / residual / statistics of this wave
     __syncthreads();
     STAMP(5 + layer);                                                // wait at the statistics barrier
-    const float cnt = (float)(COUT * P);
-    float S = 0.0f, SS = 0.0f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) { S += red[w]; SS += red[WAVES + w]; }
-    const float mean = S / cnt;
-    const float var = fmaxf(fmaf(-mean, mean, SS / cnt), 0.0f);
-    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    // (multiplications by 1 / count and v_rsq_f32 instead of two f32 divisions and a square root + division: ~12 instead of ~50
+    // DEPENDENT vector instructions between the statistics barrier and the first epilogue instruction of every wave)
+    constexpr float inv_cnt = 1.0f / (float)(COUT * P);
+    const float S = (red[0] + red[1]) + (red[2] + red[3]), SS = (red[WAVES] + red[WAVES + 1]) + (red[WAVES + 2] + red[WAVES + 3]);
+    static_assert(WAVES == 4, "the cross-wave sums are written out for four waves");
+    const float mean = S * inv_cnt;
+    const float var = fmaxf(fmaf(-mean, mean, SS * inv_cnt), 0.0f);
+    const float rstd = __builtin_amdgcn_rsqf(var + LN_EPS);
     const float shift = -mean * rstd;
     if (SAVE && sv.rstd && threadIdx.x == 0) *sv.rstd = rstd;
 
@@ -306,6 +330,27 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         // threads writes x^ to HBM as whole 2*COUT-byte rows, applies the affine + ReLU to what it just read (so the
         // backward, which recomputes y = x^ * w + b from the stored x^, sees the same ReLU mask) and leaves the activation
         // in the tile and in HBM -- coalesced 16-B stores instead of 8-B quads scattered from the accumulator layout.
+        // Round 5: the row pass is a two-stage pipeline over batches of CH items (like the backward's): the LayerNorm parameters of
+        // batch b + 1 are requested before batch b is consumed, batch 0 already before the x^ writes and the barrier.  As one rolled loop
+        // (hipcc does not pipeline it) every item exposed an L2 round trip: ds_read -> two 16-byte loads -> wait -> compute -> stores.
+        constexpr int C8 = COUT / 8, ITEMS = P * C8, NIT = (ITEMS + THREADS - 1) / THREADS, CH = NIT < 5 ? NIT : 5, NB = (NIT + CH - 1) / CH;
+        int tid_l = threadIdx.x;
+        asm volatile("" : "+v"(tid_l));                                // (keeps the item addresses out of the sample loop's hoisted set)
+        f16x8 l0[2][CH], l1[2][CH];
+        auto request = [&](int bt) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int k = bt * CH + j;
+                if (k < NIT) {
+                    const int q = min(tid_l + k * THREADS, ITEMS - 1);   // clamped: the tail threads re-load the last item and discard it
+                    const _Float16 *lq = reinterpret_cast<const _Float16 *>(lp.ln) + (size_t)q * 16;   // (p * COUT + part * 8) * 2
+                    l0[bt & 1][j] = *reinterpret_cast<const f16x8 *>(lq);
+                    l1[bt & 1][j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+                }
+            }
+        };
+        request(0);
+        POL_PIN();
 #pragma unroll
         for (int mi = 0; mi < MW; ++mi) {
             const int ch0 = (m0 + mi) * 16 + 4 * kg;
@@ -321,21 +366,30 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
         }
         __syncthreads();
         bf16x8 *xdst = reinterpret_cast<bf16x8 *>(sv.xhat), *adst = reinterpret_cast<bf16x8 *>(sv.act);
-        for (int q = threadIdx.x; q < P * (COUT / 8); q += THREADS) {
-            const int p = q / (COUT / 8), part = q - p * (COUT / 8);
-            bf16 *tp = tile + pos_of(p) * CSF + part * 8;
-            const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(tp);
-            if (xdst) xdst[q] = xv;
-            const _Float16 *lq = reinterpret_cast<const _Float16 *>(lp.ln) + ((size_t)p * COUT + part * 8) * 2;
-            const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lq), l1 = *reinterpret_cast<const f16x8 *>(lq + 8);
-            bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (bf16)fmaxf(fmaf((float)xv[e], (float)l0[e], (float)l0[4 + e]), 0.0f);
-                o[4 + e] = (bf16)fmaxf(fmaf((float)xv[4 + e], (float)l1[e], (float)l1[4 + e]), 0.0f);
+        for (int bt = 0; bt < NB; ++bt) {
+            if (bt + 1 < NB) request(bt + 1);
+            POL_PIN();
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int k = bt * CH + j, q = tid_l + k * THREADS;
+                if (k < NIT && q < ITEMS) {
+                    const int p = q / C8, part = q - p * C8;
+                    bf16 *tp = tile + pos_of(p) * CSF + part * 8;
+                    const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(tp);
+                    if (xdst) xdst[q] = xv;
+                    const f16x8 w0 = l0[bt & 1][j], w1 = l1[bt & 1][j];
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (bf16)fmaxf(fmaf((float)xv[e], (float)w0[e], (float)w0[4 + e]), 0.0f);
+                        o[4 + e] = (bf16)fmaxf(fmaf((float)xv[4 + e], (float)w1[e], (float)w1[4 + e]), 0.0f);
+                    }
+                    *reinterpret_cast<bf16x8 *>(tp) = o;
+                    if (adst) adst[q] = o;
+                }
             }
-            *reinterpret_cast<bf16x8 *>(tp) = o;
-            if (adst) adst[q] = o;
+            POL_PIN();
         }
         __syncthreads();
     } else {
@@ -486,10 +540,10 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
             conv_ln_relu<64, 128, 2, 10, false, false, true>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2, LayerSave{ xh2, ac2, rs + 2 });
             conv_ln_relu<128, 128, 2, 10, false, true, true>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3, LayerSave{ xh3, nullptr, rs + 3 });
         } else {
-        conv_ln_relu<32, 32, 1, 5, false, false, false, TN>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
-        conv_ln_relu<32, 64, 1, 10, false, false, false, TN>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
-        conv_ln_relu<64, 128, 2, 10, false, false, false, TN>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2);
-        conv_ln_relu<128, 128, 2, 10, false, true, false, TN>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3);
+            conv_ln_relu<32, 32, 1, 5, false, false, false, TN>(prm.layer[0], tile, red, lane_i, wave & 1, (wave >> 1) * 5, 5, stamp_prev, 0);
+            conv_ln_relu<32, 64, 1, 10, false, false, false, TN>(prm.layer[1], tile, red, lane_i, wave, 0, 10, stamp_prev, 1);
+            conv_ln_relu<64, 128, 2, 10, false, false, false, TN>(prm.layer[2], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 2);
+            conv_ln_relu<128, 128, 2, 10, false, true, false, TN>(prm.layer[3], tile, red, lane_i, wave * 2, 0, 10, stamp_prev, 3);
         }
         // features, channels-last [150][128] bf16 (the FC weights are permuted to this order on the host)
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * P * 128);
@@ -877,19 +931,6 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
 // dy and dz go to HBM (the parameter gradients are batch reductions / GEMMs over them), dz also into the LDS tile
 // as the B operand of the transposed convolution, whose result da' returns to the tile as bf16 for the next layer.
 
-// GEMM core of conv_ln_relu (same fragment layouts, same software pipeline), accumulators handed back to the caller.
-template <int CIN, int COUT, int MW, int NW>
-__device__ __forceinline__ void conv_gemm(const void *w, const bf16 *tile, int lane, int m0, int n0, f32x4 (&acc)[MW][NW])
-{
-#pragma unroll
-    for (int mi = 0; mi < MW; ++mi)
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.0f;
-    conv_gemm_rows<CIN, MW, NW, NW == H>(w, tile, lane, m0, n0, acc);
-}
-
 // The LayerNorm / ReLU backward does not need the accumulator layout: da goes through the LDS tile as bf16 and ALL 256
 // threads walk the sample row by row (8 channels = 16 B per item), so every HBM access is a coalesced 16-byte piece of a
 // whole row, the work is balanced over the block, and almost nothing is live across the reductions -- the kernel fits two
@@ -955,7 +996,7 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
     bf16x8 (&xc)[NIT] = rg.xc;                           // x^ of the thread's items
     f16x8 (&l0)[2][CH] = rg.l0, (&l1)[2][CH] = rg.l1;
     f16x8 gc[NIT];                                       // their 8 LayerNorm weights
-    float s1 = 0.0f, s2 = 0.0f;
+    float s1c[2] = { 0.0f, 0.0f }, s2c[2] = { 0.0f, 0.0f };   // two independent chains each (see conv_ln_relu's statistics; four spill this kernel: 320 B of scratch, 2.36 ms)
     bf16x8 dag[2][FROM_GLOBAL ? CH : 1];
     auto request = [&](int bt) {
         bwd_request<COUT>(rg, bt, ln_packed, xhat_n, tid);
@@ -990,8 +1031,8 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
                     const float d = fmaf(x, g, bb) > 0.0f ? (float)da[e] : 0.0f;
                     dy[e] = (bf16)d;
                     const float dxh = (float)dy[e] * g;  // from the ROUNDED dy: pass B recomputes exactly this value
-                    s1 += dxh;
-                    s2 += dxh * x;
+                    s1c[e & 1] += dxh;
+                    s2c[e & 1] += dxh * x;
                 }
                 gc[k] = gk;
 #ifndef POL_BWD_NO_DY
@@ -1002,8 +1043,8 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
         }
         POL_PIN();
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
+    float s1 = wave_sum(s1c[0] + s1c[1]);
+    float s2 = wave_sum(s2c[0] + s2c[1]);
     const int lane = tid & 63, wave = tid >> 6;
     if (lane == 0) { red[wave] = s1; red[WAVES + wave] = s2; }
     __syncthreads();
@@ -1037,23 +1078,26 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
                                                const bf16 *next_xhat)
 {
     f32x4 acc[MW][NW];
-#ifdef POL_BWD_NO_GEMM
-    for (int mi = 0; mi < MW; ++mi) for (int i = 0; i < NW; ++i) for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.001f * (float)(lane + mi + i);
-#else
-    conv_gemm<CIN_T, COUT_BELOW, MW, NW>(wt, tile, lane, m0, n0, acc);
-#endif
     const int c16 = lane & 15, kg = lane >> 4;
-    if (RESIDUAL) {                                  // z4 = conv4(a3) + b4 + a3: da3 += dz4 (this lane's own entries of the tile)
 #pragma unroll
-        for (int mi = 0; mi < MW; ++mi)
+    for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
+        for (int i = 0; i < NW; ++i) {
+            // z4 = conv4(a3) + b4 + a3: da3 = convT(dz4) + dz4 -- the accumulators START at this lane's own entries of the dz tile (the
+            // B operand of this GEMM, unchanged by it), read before the MFMAs instead of after them
+            acc[mi][i] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            if (RESIDUAL) {
                 const int posi = (n0 + i + 1) * PW + c16 + 1;                                // dummy column: halo, zeros
                 const bf16x4 r = *reinterpret_cast<const bf16x4 *>(tile + posi * CSF + (m0 + mi) * 16 + 4 * kg);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mi][i][e] += (float)r[e];
+                for (int e = 0; e < 4; ++e) acc[mi][i][e] = (float)r[e];
             }
-    }
+        }
+#ifdef POL_BWD_NO_GEMM
+    for (int mi = 0; mi < MW; ++mi) for (int i = 0; i < NW; ++i) for (int q = 0; q < 4; ++q) acc[mi][i][q] = 0.001f * (float)(lane + mi + i);
+#else
+    conv_gemm_rows<CIN_T, MW, NW, NW == H>(wt, tile, lane, m0, n0, acc);
+#endif
     __syncthreads();                                 // every wave has finished reading the dz tile
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi)
