@@ -30,14 +30,18 @@ def _pack_conv(w, cin_pad):
     return wk.reshape(cout // 16, k // 32, 64, 8).contiguous().to(torch.bfloat16)
 
 
-def pack_conv(w, cin_pad, transposed=False):
+def pack_conv(w, cin_pad, transposed=False, out=None):
     """_pack_conv (transposed=False) or the data-gradient form Wt[ci][8 - tap][co] = W[co][ci][tap] (transposed=True) as ONE kernel
-    (inv_policy_pack_conv) instead of five torch index kernels; `w`: f32 [Cout, Cin, 3, 3] on the GPU."""
+    (inv_policy_pack_conv) instead of five torch index kernels; `w`: f32 [Cout, Cin, 3, 3] on the GPU.  out: re-pack in place."""
     lib = L.load()
     w = w.detach().float().contiguous()
     cout, cin = int(w.shape[0]), int(w.shape[1])
     rows, kc = (cin, cout) if transposed else (cout, int(cin_pad))
-    out = torch.empty((rows // 16, 9 * kc // 32, 64, 8), dtype=torch.bfloat16, device=w.device)
+    shape = (rows // 16, 9 * kc // 32, 64, 8)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.bfloat16 or not out.is_contiguous():
+        raise ValueError(f"pack_conv: out must be contiguous bf16 {shape}")
     with torch.cuda.device(w.device):
         rc = lib.inv_policy_pack_conv(C.c_void_p(w.data_ptr()), cout, cin, int(cin_pad), int(bool(transposed)), C.c_void_p(out.data_ptr()),
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -45,12 +49,15 @@ def pack_conv(w, cin_pad, transposed=False):
     return out
 
 
-def pack_ln(weight, bias, cout):
-    """LayerNorm([C,H,W]) affine -> fp16 [H*W][C/4][weight x4 | bias x4] as one kernel (inv_policy_pack_ln)."""
+def pack_ln(weight, bias, cout, out=None):
+    """LayerNorm([C,H,W]) affine -> fp16 [H*W][C/4][weight x4 | bias x4] as one kernel (inv_policy_pack_ln).  out: re-pack in place."""
     lib = L.load()
     w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
     pixels = w.numel() // int(cout)
-    out = torch.empty((pixels, cout // 4, 8), dtype=torch.float16, device=w.device)
+    if out is None:
+        out = torch.empty((pixels, cout // 4, 8), dtype=torch.float16, device=w.device)
+    elif tuple(out.shape) != (pixels, cout // 4, 8) or out.dtype != torch.float16 or not out.is_contiguous():
+        raise ValueError(f"pack_ln: out must be contiguous fp16 {(pixels, cout // 4, 8)}")
     with torch.cuda.device(w.device):
         rc = lib.inv_policy_pack_ln(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), int(cout), pixels, C.c_void_p(out.data_ptr()),
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -93,21 +100,33 @@ class FusedPolicy:
                 self._scratch_bytes = int(self.lib.inv_policy_trunk_banded_scratch_bytes(self.H, self.W))
             if self._scratch_bytes <= 0:
                 raise ValueError(f"no fused trunk for a {self.W} x {self.H} board")
-        self._keep = []
-        params = L.InvPolicyParams()
+        # Packed operands.  After the first call they are re-packed IN PLACE (same device pointers, same `params` struct): kernels
+        # captured in a HIP graph (RolloutCollector(graph=True)) read the refreshed weights without a re-capture.  The conv bias is the
+        # live f32 parameter itself.
+        old = getattr(self, "_packed", None)
+        packed, params = [], L.InvPolicyParams()
         for i, (conv, norm) in enumerate(((p.conv1, p.norm1), (p.conv2, p.norm2), (p.conv3, p.norm3), (p.conv4, p.norm4))):
             cout = conv.out_channels
-            w = pack_conv(conv.weight, _CIN_PAD[i])
+            w = pack_conv(conv.weight, _CIN_PAD[i], out=None if old is None else old[i][0])
             b = conv.bias.detach().float().contiguous()
+            if old is not None and b.data_ptr() != old[i][1].data_ptr():         # (a bias that is not plain contiguous f32: keep the first copy's address)
+                old[i][1].copy_(b)
+                b = old[i][1]
             # LayerNorm affine, [pixel][channel/4][weight x4 | bias x4] in fp16: one 16-byte load per accumulator tile
-            ln = pack_ln(norm.weight, norm.bias, cout)
-            self._keep += [w, b, ln]
+            ln = pack_ln(norm.weight, norm.bias, cout, out=None if old is None else old[i][2])
+            packed.append((w, b, ln))
             params.layer[i] = L.InvPolicyLayer(w.data_ptr(), b.data_ptr(), ln.data_ptr())
+        self._packed = packed
         self.params = params
         # heads: the reference's sizes run on the fused kernels (heads.py / csrc/inv_heads.hip) ...
-        self.heads = HD.HeadsOperands(HD.head_tensors(p, self.actor_only), self.P) if HD.supported(p) else None
-        if self.heads is not None:
+        if HD.supported(p):
+            tensors = HD.head_tensors(p, self.actor_only)
+            if getattr(self, "heads", None) is not None:
+                self.heads.repack(tensors)
+            else:
+                self.heads = HD.HeadsOperands(tensors, self.P)
             return
+        self.heads = None
         # ... any other hidden_dim keeps the torch tail: first Linear of actor and critic concatenated; columns permuted from the
         # module's flatten order (c*150 + pixel) to the kernel's channels-last order (pixel*128 + c)
         firsts = [p.fc_actor[0]] if self.actor_only else [p.fc_actor[0], p.fc_critic[0]]

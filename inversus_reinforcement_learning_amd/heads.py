@@ -40,13 +40,17 @@ def supported(policy):
             and c[2].out_features == MID and c[4].out_features == 1 and (a[0].in_features - 4) % 256 == 0)
 
 
-def _pack_fc1(weights, pixels):
-    """[256, 128 P + 4] f32 per head -> (wf bf16 [256 nheads, 128 P] in the trunk's feature order, we f32 [256 nheads, 4])."""
+def _pack_fc1(weights, pixels, out=None):
+    """[256, 128 P + 4] f32 per head -> (wf bf16 [256 nheads, 128 P] in the trunk's feature order, we f32 [256 nheads, 4]).
+    out = (wf, we): re-pack into existing buffers (same device pointers: a captured HIP graph that reads them stays valid)."""
     lib = L.load()
     dev = weights[0].device
     n = len(weights)
-    wf = torch.empty((HID * n, 128 * pixels), dtype=torch.bfloat16, device=dev)
-    we = torch.empty((HID * n, 4), dtype=torch.float32, device=dev)
+    if out is None:
+        wf = torch.empty((HID * n, 128 * pixels), dtype=torch.bfloat16, device=dev)
+        we = torch.empty((HID * n, 4), dtype=torch.float32, device=dev)
+    else:
+        wf, we = out
     with torch.cuda.device(dev):
         for i, w in enumerate(weights):
             w = w.detach()
@@ -56,29 +60,34 @@ def _pack_fc1(weights, pixels):
     return wf, we
 
 
-def _pack_fragments(mats, need_t):
-    """mats: per head (W2 [128, 256], W3 [13 | 1, 128]) f32 -> fragment tensors {w2, w3, w2t, w3t} per head, one launch."""
+def _pack_fragments(mats, need_t, out=None):
+    """mats: per head (W2 [128, 256], W3 [13 | 1, 128]) f32 -> fragment tensors {w2, w3, w2t, w3t} per head, one launch.
+    out: the list a previous call returned -- the fragments are re-packed into those tensors."""
     lib = L.load()
     dev = mats[0][0].device
-    lst, out, k = L.InvHeadsPackList(), [], 0
-    for w2, w3 in mats:
+    lst, res, k = L.InvHeadsPackList(), [], 0
+    for hi, (w2, w3) in enumerate(mats):
         w2, w3 = w2.detach(), w3.detach()
         for w, shape in ((w2, (MID, HID)), (w3, (w3.shape[0], MID))):
             if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != shape:
                 raise ValueError(f"head Linear must be contiguous f32 {shape}, got {tuple(w.shape)} {w.dtype}")
-        d = {"w2": torch.empty(MID * HID, dtype=torch.bfloat16, device=dev), "w3": torch.empty(16 * MID, dtype=torch.bfloat16, device=dev)}
+        if out is not None:
+            d = out[hi]
+        else:
+            d = {"w2": torch.empty(MID * HID, dtype=torch.bfloat16, device=dev), "w3": torch.empty(16 * MID, dtype=torch.bfloat16, device=dev)}
+            if need_t:
+                d["w2t"] = torch.empty(HID * MID, dtype=torch.bfloat16, device=dev)
+                d["w3t"] = torch.empty(MID * 32, dtype=torch.bfloat16, device=dev)
         items = [(w2, d["w2"], MID, HID, HID, 0, MID, HID), (w3, d["w3"], w3.shape[0], MID, MID, 0, 16, MID)]
         if need_t:
-            d["w2t"] = torch.empty(HID * MID, dtype=torch.bfloat16, device=dev)
-            d["w3t"] = torch.empty(MID * 32, dtype=torch.bfloat16, device=dev)
             items += [(w2, d["w2t"], HID, MID, HID, 1, HID, MID), (w3, d["w3t"], MID, w3.shape[0], MID, 1, MID, 32)]
         for src, dst, rows, cols, ld, tr, mpad, kpad in items:
             lst.item[k] = L.InvHeadsPackItem(src.data_ptr(), dst.data_ptr(), rows, cols, ld, tr, mpad, kpad)
             k += 1
-        out.append(d)
+        res.append(d)
     with torch.cuda.device(dev):
         L.raise_for(lib.inv_heads_pack(C.byref(lst), k, _stream()), lib)
-    return out
+    return res
 
 
 class HeadsOperands:
@@ -86,19 +95,41 @@ class HeadsOperands:
 
     def __init__(self, heads, pixels, need_t=False):
         """heads: per head the six tensors (W1, b1, W2, b2, W3, b3) of its nn.Sequential."""
-        self.nheads = len(heads)
-        self.wf, self.we = _pack_fc1([h[0] for h in heads], pixels)
-        self.b1 = torch.cat([h[1].detach().float() for h in heads]).contiguous()
-        frags = _pack_fragments([(h[2], h[4]) for h in heads], need_t)
-        self.keep = [frags] + [[h[3].detach().float().contiguous(), h[5].detach().float().contiguous()] for h in heads]
-        p = L.InvHeadsParams()
-        for i, (f, h) in enumerate(zip(frags, heads)):
-            p.w2[i], p.w3[i] = f["w2"].data_ptr(), f["w3"].data_ptr()
-            if need_t:
-                p.w2t[i], p.w3t[i] = f["w2t"].data_ptr(), f["w3t"].data_ptr()
-            p.b2[i], p.b3[i] = self.keep[1 + i][0].data_ptr(), self.keep[1 + i][1].data_ptr()
-        p.we, p.b1 = self.we.data_ptr(), self.b1.data_ptr()
-        self.params = p
+        self.nheads, self.pixels, self.need_t = len(heads), int(pixels), bool(need_t)
+        self.wf = self.we = self.b1 = self.frags = None
+        self.repack(heads)
+
+    def repack(self, heads):
+        """(Re-)pack the parameters.  After the first call everything is written IN PLACE -- wf / we / b1 / the fragment tensors keep
+        their device pointers and b2 / b3 are read from the live parameters -- so kernels captured in a HIP graph
+        (RolloutCollector(graph=True)) see the new weights without a re-capture."""
+        if len(heads) != self.nheads:
+            raise ValueError(f"repack: {self.nheads} heads were packed, got {len(heads)}")
+        first = self.wf is None
+        self.wf, self.we = _pack_fc1([h[0] for h in heads], self.pixels, None if first else (self.wf, self.we))
+        b1 = torch.cat([h[1].detach().float() for h in heads]).contiguous()
+        if first:
+            self.b1 = b1
+        else:
+            self.b1.copy_(b1)
+        self.frags = _pack_fragments([(h[2], h[4]) for h in heads], self.need_t, None if first else self.frags)
+        small = [[h[3].detach().float().contiguous(), h[5].detach().float().contiguous()] for h in heads]
+        if first:
+            self.keep = [self.frags] + small
+            p = L.InvHeadsParams()
+            for i, f in enumerate(self.frags):
+                p.w2[i], p.w3[i] = f["w2"].data_ptr(), f["w3"].data_ptr()
+                if self.need_t:
+                    p.w2t[i], p.w3t[i] = f["w2t"].data_ptr(), f["w3t"].data_ptr()
+                p.b2[i], p.b3[i] = small[i][0].data_ptr(), small[i][1].data_ptr()
+            p.we, p.b1 = self.we.data_ptr(), self.b1.data_ptr()
+            self.params = p
+        else:
+            for i, (b2, b3) in enumerate(small):                                # views of the live parameters, or (non-f32 / strided) copies
+                if b2.data_ptr() != self.keep[1 + i][0].data_ptr():
+                    self.keep[1 + i][0].copy_(b2)
+                if b3.data_ptr() != self.keep[1 + i][1].data_ptr():
+                    self.keep[1 + i][1].copy_(b3)
 
     def forward(self, feat, extra, save=False):
         """feat bf16 [B, 128 P], extra f32 [B, 4] -> logits f32 [B, 13], value f32 [B, 1] | None (+ (pre... h, a2) when save)."""

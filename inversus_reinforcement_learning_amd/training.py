@@ -52,8 +52,15 @@ class RolloutCollector:
                a1 / a2 come from one batched forward of `policy` / `opponent` each (the reference
                does N batch-of-1 forwards, training.py:249-258)."""
 
-    def __init__(self, batch, agent, opponent=None, packed_obs=None, record_opponent_actions=False, opponent_stream=False):
+    def __init__(self, batch, agent, opponent=None, packed_obs=None, record_opponent_actions=False, opponent_stream=False, graph=False):
         self.batch, self.agent, self.opponent = batch, agent, opponent
+        # graph: capture the act -> step -> store chain of a whole rollout in ONE HIP graph (SURVEY 7 step 9; training.py:117-157 is the
+        # loop it replaces) and replay it per rollout: see _collect_graphed.  Needs fused actors (their packed weights are refreshed in
+        # place, so the captured kernels read the updated policy) and the main stream only.
+        self.graph = bool(graph)
+        self._graph_state, self._graph_warm = None, False
+        if self.graph and (agent.fused is None or (opponent is not None and hasattr(opponent, "parameters")) or opponent_stream):
+            raise ValueError("graph=True needs fused actors (PPOAgent(fused_act=True), a FusedPolicy opponent) on one stream")
         # opponent_stream: the frozen opponent's forward (trunk, first Linear, heads, sampling) on a second HIP stream beside the
         # learner's, joined before the env step.  Safe since round 4: every kernel of both forwards is this library's own and none
         # waits on another workgroup (the library GEMM that used to sit there was a stream-K kernel sized for the whole chip, and
@@ -95,9 +102,71 @@ class RolloutCollector:
 
     def collect(self, steps):
         with roctx.range("rollout.collect"):
+            if self.graph:
+                return self._collect_graphed(steps)
             return self._collect(steps)
 
+    _AGENT_BUFFERS = ("obs_grid_buffer", "obs_extra_buffer", "action_buffer", "log_prob_buffer", "reward_buffer", "value_buffer", "done_buffer")
+
+    def _collect_graphed(self, steps):
+        """One rollout = one graph launch.  The first rollout runs eagerly (allocator, lazy initialisation); the second is CAPTURED
+        (nothing executes during capture: the agent's buffers, the pending episode statistics and the recorded opponent actions are
+        filled with the graph's own tensors, which every replay overwrites) and replayed; later rollouts of the same length put the
+        same tensors back into the agent's (emptied) buffers and replay.  State that crosses rollouts lives at fixed addresses: the env
+        batch, the current observations (copied to static buffers at the end of the graph, copied out of them at its start -- the
+        rollout buffer keeps the first observation), the actors' packed weights (refreshed in place), torch's device generator
+        (graph-safe Philox offsets: every replay draws new sampling keys).  A rollout of another length (the last, shorter one of a
+        run) runs eagerly.  Host work per rollout: one graph launch + the drain, instead of ~10 launches per vector step."""
+        agent = self.agent
+        if not self._graph_warm:
+            self._graph_warm = True
+            return self._collect(steps)
+        st = self._graph_state
+        if st is not None and st["steps"] != steps:
+            return self._collect(steps)
+        if any(len(getattr(agent, name)) for name in self._AGENT_BUFFERS) or self._pending:
+            raise RuntimeError("graph=True: collect() needs empty rollout buffers (call agent.update() or agent.reset_buffers() first)")
+        if st is None:
+            dev = self.batch.device
+            static = [t.clone() for t in self.obs] + ([t.clone() for t in self.obs_p2] if self.selfplay else [])
+            n_opp = len(self.opponent_actions) if self.opponent_actions is not None else 0
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.obs = (static[0].clone(), static[1].clone())          # the rollout buffer keeps these; the static ones are overwritten below
+                if self.selfplay:
+                    self.obs_p2 = (static[2].clone(), static[3].clone())
+                self._collect_steps(steps)
+                last = list(self.obs) + (list(self.obs_p2) if self.selfplay else [])
+                for dst, src in zip(static, last):
+                    dst.copy_(src)
+            st = self._graph_state = {
+                "steps": steps, "graph": g, "static": static,
+                "buffers": {name: list(getattr(agent, name)) for name in self._AGENT_BUFFERS},
+                "pending": list(self._pending),
+                "opp": list(self.opponent_actions[n_opp:]) if self.opponent_actions is not None else None,
+            }
+            if self.opponent_actions is not None:
+                del self.opponent_actions[n_opp:]
+        else:
+            for name in self._AGENT_BUFFERS:
+                setattr(agent, name, list(st["buffers"][name]))
+            self._pending = list(st["pending"])
+        if self.opponent_actions is not None:
+            self.opponent_actions.extend(st["opp"])
+        st["graph"].replay()
+        self.obs = (st["static"][0], st["static"][1])
+        if self.selfplay:
+            self.obs_p2 = (st["static"][2], st["static"][3])
+        self._drain()
+        return steps * self.batch.num_envs
+
     def _collect(self, steps):
+        self._collect_steps(steps)
+        self._drain()
+        return steps * self.batch.num_envs
+
+    def _collect_steps(self, steps):
         b, agent = self.batch, self.agent
         for _ in range(steps):
             grid, extra = self.obs
@@ -124,8 +193,6 @@ class RolloutCollector:
             if self.selfplay:
                 self.obs_p2 = (r.obs_p2, r.extra_p2)
             self._pending.append((r.done, r.episode_return, r.episode_steps, r.info_flags))
-        self._drain()
-        return steps * b.num_envs
 
     def _drain(self):
         """Episode statistics of the steps collected since the last call: ONE gather + device->host copy per rollout
@@ -181,7 +248,7 @@ def _make(num_envs_total, opponent_type, difficulty, seed, width, height):
     return rank, world_size, batch, policy
 
 
-def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, width, height, agent_kwargs, verbose):
+def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, width, height, agent_kwargs, verbose, graph=False):
     rank, world_size, batch, policy = _make(num_envs, "dummy" if mode == "vs_dummy" else "selfplay", difficulty,
                                             seed, width, height)
     if load_model:
@@ -198,7 +265,7 @@ def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, w
     if opponent is not None and agent.fused is not None:
         from .fused_policy import FusedPolicy
         opponent = FusedPolicy(opp_module, actor_only=True)         # the frozen opponent acts through the fused trunk too; no critic
-    collector = RolloutCollector(batch, agent, opponent)
+    collector = RolloutCollector(batch, agent, opponent, graph=graph)
     logger = TrainingLogger(log_dir) if (log_dir and rank == 0) else None
 
     steps_per_env = max(2048 // num_envs, 128)                      # training.py:105-107
@@ -242,14 +309,14 @@ def _train(mode, num_envs, total_steps, log_dir, difficulty, load_model, seed, w
 
 
 def train_vs_dummy(num_envs=1, total_steps=500_000, log_dir="runs/inversus_vs_dummy", opponent_difficulty="easy",
-                   load_model=None, *, seed=None, width=15, height=10, agent_kwargs=None, verbose=True):
+                   load_model=None, *, seed=None, width=15, height=10, agent_kwargs=None, verbose=True, graph=False):
     return _train("vs_dummy", num_envs, total_steps, log_dir, opponent_difficulty, load_model, seed, width, height,
-                  agent_kwargs, verbose)
+                  agent_kwargs, verbose, graph)
 
 
 def train_selfplay(num_envs=1, total_steps=500_000, log_dir="runs/inversus_selfplay", load_model=None, *,
-                   seed=None, width=15, height=10, agent_kwargs=None, verbose=True):
-    return _train("selfplay", num_envs, total_steps, log_dir, "easy", load_model, seed, width, height, agent_kwargs, verbose)
+                   seed=None, width=15, height=10, agent_kwargs=None, verbose=True, graph=False):
+    return _train("selfplay", num_envs, total_steps, log_dir, "easy", load_model, seed, width, height, agent_kwargs, verbose, graph)
 
 
 def main(argv=None):
@@ -272,6 +339,9 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=None, help="PPO minibatch size (reference default 512)")
     ap.add_argument("--epochs", type=int, default=None, help="PPO epochs per rollout (reference default 4)")
     ap.add_argument("--lr", type=float, default=None)
+    ap.add_argument("--graph", action="store_true",
+                    help="with --fused: capture a whole rollout (act -> step -> store per vector step) in one HIP graph and replay it per "
+                         "rollout -- one launch instead of ~10 per vector step; what small --num_envs runs are bound by")
     ap.add_argument("--gae_layout", choices=["per_env", "reference_flat"], default=None,
                     help="per_env (default): each env's own trajectory; reference_flat: the reference's single chain over the "
                          "env-interleaved buffer (ppo_agent.py:127-157) -- what its own runs were trained with")
@@ -283,8 +353,8 @@ def main(argv=None):
         kw.update(fused_act=True, fused_update=True)
     if args.mode == "vs_dummy":
         return train_vs_dummy(args.num_envs, args.total_steps, log_dir, args.opponent_difficulty, args.load_model, seed=args.seed,
-                              agent_kwargs=kw)
-    return train_selfplay(args.num_envs, args.total_steps, log_dir, args.load_model, seed=args.seed, agent_kwargs=kw)
+                              agent_kwargs=kw, graph=args.graph)
+    return train_selfplay(args.num_envs, args.total_steps, log_dir, args.load_model, seed=args.seed, agent_kwargs=kw, graph=args.graph)
 
 
 if __name__ == "__main__":

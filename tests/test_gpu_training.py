@@ -236,3 +236,108 @@ def test_c1_at_the_references_hyper_parameters_stays_in_the_reference_held_band(
     assert 240.0 <= float(last["avg_ep_len"]) <= 460.0
     assert 2.35 <= float(last["entropy"]) <= np.log(13)
     assert all(np.isfinite(float(x[k])) for x in rows for k in ("policy_loss", "value_loss", "avg_reward"))
+
+
+def test_fused_policy_refresh_is_in_place_and_equals_a_fresh_packing():
+    """Round 5 (graph capture): FusedPolicy.refresh() re-packs into the SAME device buffers (the kernel-argument struct does not
+    change), and what it computes afterwards is what a freshly built FusedPolicy of the updated module computes, bit for bit."""
+    import torch
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    torch.manual_seed(3)
+    pol = InversusCNNPolicy(12, 10, 15, 4).cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    grid = (torch.rand(96, 12, 10, 15, device="cuda", generator=g) < 0.2).float()
+    extra = torch.rand(96, 4, device="cuda", generator=g)
+    for kw in ({}, {"actor_only": True}, {"train_numerics": True}):
+        f = FusedPolicy(pol, **kw)
+        ptrs = [(l.w, l.bias, l.ln) for l in f.params.layer]
+        hp = (f.heads.wf.data_ptr(), f.heads.we.data_ptr(), f.heads.b1.data_ptr(), [d["w2"].data_ptr() for d in f.heads.frags])
+        lo0, _ = f(grid, extra)
+        with torch.no_grad():
+            for prm in pol.parameters():
+                prm.add_(0.05 * torch.randn_like(prm))
+        f.refresh()
+        assert [(l.w, l.bias, l.ln) for l in f.params.layer] == ptrs
+        assert (f.heads.wf.data_ptr(), f.heads.we.data_ptr(), f.heads.b1.data_ptr(), [d["w2"].data_ptr() for d in f.heads.frags]) == hp
+        lo1, v1 = f(grid, extra)
+        lo2, v2 = FusedPolicy(pol, **kw)(grid, extra)
+        assert torch.equal(lo1, lo2) and (v1 is None or torch.equal(v1, v2)) and not torch.equal(lo0, lo1)
+
+
+@pytest.mark.parametrize("mode", ["dummy", "selfplay"])
+def test_graph_captured_collector_steps_the_env_like_the_oracle_and_sees_refreshed_weights(mode):
+    """RolloutCollector(graph=True) (the loop of training.py:117-157 as ONE HIP graph per rollout): rollout 1 eager,
+    rollout 2 captured + replayed, rollouts 3-4 replayed, a PPO update between them.  (a) Every stored transition equals the oracle
+    replaying the stored actions (rewards f32 bits, dones, next observations, auto-resets) across all four rollouts -- the env state,
+    the observations carried from rollout to rollout and the episode statistics survive capture and replay; (b) the log-probs /
+    values stored by a REPLAY are what the current (updated, re-packed in place) policy computes on the stored observations -- the
+    captured kernels read the refreshed weights; (c) the sampled actions differ between replays (graph-safe generator offsets)."""
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch, unpack_obs
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    from oracle import oracle as orc
+    n, T = 64, 12
+    seeds = 900 + np.arange(n, dtype=np.int64)
+    selfplay = mode == "selfplay"
+    b = DeviceEnvBatch(n, opponent="selfplay" if selfplay else "dummy", difficulty="hard", opp_seed=11, max_episode_steps=9)
+    b.seed(seeds); b.reset()
+    torch.manual_seed(0)
+    agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), fused_act=True, fused_update=True, batch_size=n * T, epochs=1, lr=3e-3)
+    opp = FusedPolicy(InversusCNNPolicy(12, 10, 15, 4).cuda().eval(), actor_only=True) if selfplay else None
+    col = RolloutCollector(b, agent, opp, graph=True, record_opponent_actions=selfplay)
+    ob = orc.OracleBatch(n, max_episode_steps=9)
+    ob.seed_reset(seeds)
+    first_actions, episodes = [], 0
+    for rollout in range(4):
+        col.collect(T)
+        assert (col._graph_state is not None) == (rollout >= 1)
+        assert len(agent.obs_grid_buffer) == T
+        a2s = col.opponent_actions[-T:] if selfplay else [None] * T
+        for t in range(T):
+            a1 = agent.action_buffer[t].cpu().numpy().astype(np.uint8)
+            a2 = a2s[t].cpu().numpy().astype(np.uint8) if selfplay else None
+            o_obs, o_extra, o_r32, _, o_done, _ = ob.step(a1, a2, hard=True, opp_seed=11)
+            assert bits_eq(agent.reward_buffer[t].cpu().numpy(), o_r32), (rollout, t)
+            assert np.array_equal(agent.done_buffer[t].cpu().numpy(), o_done.astype(bool)), (rollout, t)
+            nxt = agent.obs_grid_buffer[t + 1] if t + 1 < T else col.obs[0]
+            assert bits_eq(unpack_obs(nxt, 10, 15).cpu().numpy(), o_obs), (rollout, t)
+            episodes += int(o_done.sum())
+        assert col.episodes_finished == episodes
+        first_actions.append(agent.action_buffer[0].clone())
+        # (b) stored log-probs / values of this rollout = the current policy on the stored observations (same kernels, same batch size)
+        with torch.no_grad():
+            for t in (0, T - 1):
+                lo, v = agent.fused(agent.obs_grid_buffer[t], agent.obs_extra_buffer[t])
+                lp = torch.distributions.Categorical(logits=lo.float(), validate_args=False).log_prob(agent.action_buffer[t])
+                assert float((lp - agent.log_prob_buffer[t]).abs().max()) < 1e-6 and torch.equal(v.float().squeeze(-1), agent.value_buffer[t])
+        before = agent.policy.conv1.weight.detach().clone()
+        agent.update()
+        assert not torch.equal(before, agent.policy.conv1.weight.detach())
+    assert episodes > 0
+    assert not torch.equal(first_actions[2], first_actions[3])                             # new sampling keys in every replay
+
+
+def test_graph_collector_refuses_what_it_cannot_capture():
+    import torch
+    from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
+    from inversus_reinforcement_learning_amd.policies import InversusCNNPolicy
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    from inversus_reinforcement_learning_amd.training import RolloutCollector
+    b = DeviceEnvBatch(8, opponent="dummy")
+    b.seed(np.arange(8, dtype=np.int64)); b.reset()
+    with pytest.raises(ValueError, match="fused"):
+        RolloutCollector(b, PPOAgent(InversusCNNPolicy(12, 10, 15, 4)), graph=True)          # the f32 module as the actor
+    agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), fused_act=True)
+    col = RolloutCollector(b, agent, graph=True)
+    col.collect(3)
+    with pytest.raises(RuntimeError, match="empty rollout buffers"):
+        col.collect(3)                                                                       # buffers not consumed
+    agent.reset_buffers()
+    col.collect(3)                                                                           # captured + replayed
+    agent.reset_buffers()
+    col.collect(5)                                                                           # another length: eager
+    assert len(agent.obs_grid_buffer) == 5 and col._graph_state["steps"] == 3
