@@ -286,12 +286,12 @@ def test_graph_captured_collector_steps_the_env_like_the_oracle_and_sees_refresh
     b = DeviceEnvBatch(n, opponent="selfplay" if selfplay else "dummy", difficulty="hard", opp_seed=11, max_episode_steps=9)
     b.seed(seeds); b.reset()
     torch.manual_seed(0)
-    agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), fused_act=True, fused_update=True, batch_size=n * T, epochs=1, lr=3e-3)
+    agent = PPOAgent(InversusCNNPolicy(12, 10, 15, 4), fused_act=True, fused_update=True, batch_size=n * T, epochs=1, lr=3e-4)
     opp = FusedPolicy(InversusCNNPolicy(12, 10, 15, 4).cuda().eval(), actor_only=True) if selfplay else None
     col = RolloutCollector(b, agent, opp, graph=True, record_opponent_actions=selfplay)
     ob = orc.OracleBatch(n, max_episode_steps=9)
     ob.seed_reset(seeds)
-    first_actions, episodes = [], 0
+    all_actions, episodes = [], 0
     for rollout in range(4):
         col.collect(T)
         assert (col._graph_state is not None) == (rollout >= 1)
@@ -307,7 +307,7 @@ def test_graph_captured_collector_steps_the_env_like_the_oracle_and_sees_refresh
             assert bits_eq(unpack_obs(nxt, 10, 15).cpu().numpy(), o_obs), (rollout, t)
             episodes += int(o_done.sum())
         assert col.episodes_finished == episodes
-        first_actions.append(agent.action_buffer[0].clone())
+        all_actions.append(torch.stack(agent.action_buffer).clone())
         # (b) stored log-probs / values of this rollout = the current policy on the stored observations (same kernels, same batch size)
         with torch.no_grad():
             for t in (0, T - 1):
@@ -318,7 +318,9 @@ def test_graph_captured_collector_steps_the_env_like_the_oracle_and_sees_refresh
         agent.update()
         assert not torch.equal(before, agent.policy.conv1.weight.detach())
     assert episodes > 0
-    assert not torch.equal(first_actions[2], first_actions[3])                             # new sampling keys in every replay
+    # (c) new sampling keys in every replay: the 768 actions of two replays of a near-uniform 13-way policy cannot coincide
+    assert all(int(a.unique().numel()) > 6 for a in all_actions)                            # (the policy has not collapsed: the check means something)
+    assert not torch.equal(all_actions[1], all_actions[2]) and not torch.equal(all_actions[2], all_actions[3])
 
 
 def test_graph_collector_refuses_what_it_cannot_capture():

@@ -42,17 +42,18 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="+", default=[0, 1, 2])
     ap.add_argument("--paths", nargs="+", default=["f32", "fused"])
     ap.add_argument("--gae_layout", default="reference_flat")
+    ap.add_argument("--graph", action="store_true", help="fused path: --graph (one HIP graph per rollout); tag 'fusedgraph'")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "c1"))
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     summary = {"reference": REFERENCE, "runs": []}
     for path in args.paths:
         for seed in args.seeds:
-            tag = f"c1_{path}_{args.gae_layout}_seed{seed}"
+            tag = f"c1_{path}{'graph' if (args.graph and path == 'fused') else ''}_{args.gae_layout}_seed{seed}"
             log_dir = os.path.join(args.out, "run_" + tag)
             cmd = [sys.executable, "-m", "inversus_reinforcement_learning_amd.training", "--mode", "vs_dummy", "--num_envs", "4",
                    "--total_steps", str(args.total_steps), "--opponent_difficulty", "easy", "--seed", str(seed), "--log_dir", log_dir,
-                   "--gae_layout", args.gae_layout] + (["--fused"] if path == "fused" else [])
+                   "--gae_layout", args.gae_layout] + (["--fused"] if path == "fused" else []) + (["--graph"] if (args.graph and path == "fused") else [])
             t0 = time.time()
             p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             secs = time.time() - t0
@@ -76,7 +77,7 @@ def main():
                    "last10": {k: stat(k) for k in ("win_rate", "avg_ep_len", "entropy", "avg_reward")}}
             summary["runs"].append(rec)
             print(json.dumps(rec), flush=True)
-    with open(os.path.join(args.out, f"c1_summary_{args.gae_layout}.json"), "w") as fh:
+    with open(os.path.join(args.out, f"c1_summary_{args.gae_layout}{'_graph' if args.graph else ''}.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     print("| path | seed | win rate (last 10 rows: min / max / mean) | avg_ep_len | entropy | episodes | s |")
     print("|---|---|---|---|---|---|---|")
