@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of alternative builds of the library on the fused trunk: python tools/trunk_ab.py lib1.so lib2.so ...
-Each build runs in its own process (INVERSUS_HIP_LIB); prints ms per 16384-sample forward (min / median of 7)."""
+"""A/B of alternative builds of the library on the fused trunk: python tools/trunk_ab.py lib1.so lib2.so[@VAR=VALUE[,VAR=VALUE]] ...
+Each build runs in its own process (INVERSUS_HIP_LIB, plus the variables after `@`, under a 300-s timeout); prints ms per
+16384-sample forward (min / median of 7)."""
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -47,7 +48,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     print(json.dumps({"packed_min_ms": round(min(outb), 4), "packed_median_ms": round(sorted(outb)[3], 4), "min_ms": round(min(out), 4), "median_ms": round(sorted(out)[3], 4), "checksum": float(ref.abs().sum()), "max_err": round(float(err.max()), 4), "mean_err": round(float(err.mean()), 5), "max_err_vs_fp16_ln_ref": round(float(err16.max()), 4), "feat_absmax": round(float(want.abs().max()), 2)}))
     sys.exit(0)
 for rep in range(2):
-    for lib in sys.argv[1:]:
+    for spec in sys.argv[1:]:
+        lib, _, extra = spec.partition("@")
         env = dict(os.environ, INVERSUS_HIP_LIB=os.path.join(ROOT, lib))
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
-        print(lib, r.stdout.strip() or r.stderr[-400:], flush=True)
+        env.update(dict(kv.split("=", 1) for kv in extra.split(",") if kv))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=300)
+            print(spec, r.stdout.strip() or r.stderr[-400:], flush=True)
+        except subprocess.TimeoutExpired:
+            print(spec, "TIMEOUT after 300 s -- stopping (no further GPU step after a hung one)", flush=True)
+            sys.exit(1)
