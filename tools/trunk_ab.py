@@ -16,6 +16,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         for nm in (pol.norm1, pol.norm2, pol.norm3, pol.norm4):
             nm.weight.add_(0.3 * torch.randn_like(nm.weight)); nm.bias.add_(0.3 * torch.randn_like(nm.bias))
     f = FusedPolicy(pol)
+    if os.environ.get("INVERSUS_TRUNK32") == "1":
+        # experiment builds only (profiles/r05_trunk_experiments.md, section 7): layers 3 / 4 of the inference kernel run on
+        # v_mfma_f32_32x32x16_bf16 and read their weights in that shape's A-fragment order:
+        #   [Cout/32][tap * Cin/16 + kk][lane = 32 h + r][j] = W[32 mt + r][16 kk + 8 h + j][tap]
+        def pack32(w):
+            cout, cin = w.shape[:2]
+            wk = w.detach().float().permute(0, 2, 3, 1).reshape(cout // 32, 32, 9, cin // 16, 2, 8).permute(0, 2, 3, 4, 1, 5)
+            return wk.reshape(cout // 32, 9 * cin // 16, 64, 8).contiguous().to(torch.bfloat16)
+        keep32 = [pack32(pol.conv3.weight), pack32(pol.conv4.weight)]
+        f.params.layer[2].w, f.params.layer[3].w = keep32[0].data_ptr(), keep32[1].data_ptr()
     g = (torch.rand(n, 12, 10, 15, device="cuda") < 0.2).float()
     ref = f.features(g).float()
     with torch.no_grad():
