@@ -26,7 +26,7 @@ from .device_env import gae as device_gae, unpack_obs
 class PPOAgent:
     def __init__(self, policy, lr=1e-4, gamma=0.99, lam=0.95, clip_ratio=0.2, epochs=4, batch_size=512,
                  entropy_coef=0.02, value_coef=0.1, device="cuda", *, gae_layout="per_env", max_grad_norm=0.5,
-                 fused_act=False, update_autocast=None, fused_update=False):
+                 fused_act=False, update_autocast=None, fused_update=False, graph_update=False):
         self.device = torch.device(device)
         self.policy = policy.to(self.device)
         self.gamma, self.lam, self.clip_ratio = gamma, lam, clip_ratio
@@ -67,6 +67,11 @@ class PPOAgent:
             from .fused_train import _trunk_params
             covered = {id(q) for q in _trunk_params(self.policy)} | {id(t) for h in HD.head_tensors(self.policy) for t in h}
             self.direct_grads = HD.supported(self.policy) and covered == {id(q) for q in self.flat_adam.params}
+        # graph_update (with fused_update, single rank): a full-size minibatch's forward + loss + backward -- ~160 launches that a batch of
+        # 512 is bound by -- is captured ONCE in a HIP graph and replayed per minibatch: index_select into static input buffers, one graph
+        # launch, then the clip + Adam kernels (their bias corrections are host-side scalars of the step count: outside the graph)
+        self.graph_update = bool(graph_update) and self.direct_grads
+        self._mb_graph, self._mb_graph_warm = None, False
         self.fused = None
         if fused_act:
             from .fused_policy import FusedPolicy
@@ -163,6 +168,33 @@ class PPOAgent:
         adv, ret = self._advantages_device(last_value)
         return adv.cpu().numpy(), ret.cpu().numpy()
 
+    def _minibatch_graphed(self, fields, idx):
+        """loss_and_grads of one full-size minibatch through a captured HIP graph.  fields: the rollout's (obs_grid, obs_extra, actions,
+        old_log_probs, advantages, returns); idx: the minibatch's sample indices.  The first such minibatch runs eagerly (lazy
+        initialisation, allocator, the side stream), the second is captured and replayed, later ones gather into the same static input
+        buffers and replay.  The graph is keyed by everything that is frozen into it (shapes, dtypes, the three loss coefficients);
+        the gradients land in the flat bucket and `means` in a static tensor, exactly as in the eager call."""
+        key = (tuple((tuple(t.shape[1:]), t.dtype) for t in fields), int(idx.numel()), float(self.clip_ratio), float(self.value_coef),
+               float(self.entropy_coef))
+        st = self._mb_graph
+        if st is None or st["key"] != key:
+            if not self._mb_graph_warm:
+                self._mb_graph_warm = True
+                return self.train_fwd.loss_and_grads(*[t[idx] for t in fields], self.clip_ratio, self.value_coef, self.entropy_coef)
+            static = [torch.empty((idx.numel(),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in fields]
+            for dst, src in zip(static, fields):
+                torch.index_select(src, 0, idx, out=dst)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                means = self.train_fwd.loss_and_grads(*static, self.clip_ratio, self.value_coef, self.entropy_coef)
+            st = self._mb_graph = {"key": key, "graph": g, "static": static, "means": means}
+        else:
+            for dst, src in zip(st["static"], fields):
+                torch.index_select(src, 0, idx, out=dst)
+        st["graph"].replay()
+        return st["means"]
+
     # ------------------------------------------------------------------ update (ppo_agent.py:159-247)
     def update(self, advantages=None, returns=None, *, permutations=None, trace=False):
         """PPO update over the stored rollout.  `advantages` / `returns` (flat, buffer order) may be
@@ -211,10 +243,13 @@ class PPOAgent:
                     with roctx.range("ppo.minibatch (fused forward + backward + clip/Adam)"):
                         # fused trunk / heads / loss kernels forward and backward without the autograd engine; every gradient is
                         # written into the flat bucket (nothing to zero), the heads' all-reduce starts before the trunk's backward
-                        means = self.train_fwd.loss_and_grads(obs_grid[idx], obs_extra[idx], actions[idx], old_log_probs[idx],
-                                                              advantages[idx], returns[idx], self.clip_ratio, self.value_coef,
-                                                              self.entropy_coef,
-                                                              after_heads=self.reducer.start_early if self.reducer is not None else None)
+                        if self.graph_update and self.reducer is None and not trace and idx.numel() == self.batch_size:
+                            means = self._minibatch_graphed((obs_grid, obs_extra, actions, old_log_probs, advantages, returns), idx)
+                        else:
+                            means = self.train_fwd.loss_and_grads(obs_grid[idx], obs_extra[idx], actions[idx], old_log_probs[idx],
+                                                                  advantages[idx], returns[idx], self.clip_ratio, self.value_coef,
+                                                                  self.entropy_coef,
+                                                                  after_heads=self.reducer.start_early if self.reducer is not None else None)
                         if self.reducer is not None:
                             self.reducer.reduce(average=False)            # SUM over ranks; the 1/world_size rides in the Adam kernel
                             grad_norm = self.flat_adam.step(grad_scale=1.0 / parallel.world()[1])

@@ -341,7 +341,8 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=None)
     ap.add_argument("--graph", action="store_true",
                     help="with --fused: capture a whole rollout (act -> step -> store per vector step) in one HIP graph and replay it per "
-                         "rollout -- one launch instead of ~10 per vector step; what small --num_envs runs are bound by")
+                         "rollout, and a minibatch's forward + loss + backward in another -- one launch instead of ~10 per vector step / "
+                         "~160 per minibatch; what small --num_envs / --batch_size runs are bound by")
     ap.add_argument("--gae_layout", choices=["per_env", "reference_flat"], default=None,
                     help="per_env (default): each env's own trajectory; reference_flat: the reference's single chain over the "
                          "env-interleaved buffer (ppo_agent.py:127-157) -- what its own runs were trained with")
@@ -350,7 +351,7 @@ def main(argv=None):
     kw = {k: v for k, v in (("batch_size", args.batch_size), ("epochs", args.epochs), ("lr", args.lr), ("gae_layout", args.gae_layout))
           if v is not None}
     if args.fused:
-        kw.update(fused_act=True, fused_update=True)
+        kw.update(fused_act=True, fused_update=True, graph_update=bool(args.graph))
     if args.mode == "vs_dummy":
         return train_vs_dummy(args.num_envs, args.total_steps, log_dir, args.opponent_difficulty, args.load_model, seed=args.seed,
                               agent_kwargs=kw, graph=args.graph)

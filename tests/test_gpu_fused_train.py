@@ -296,3 +296,50 @@ def test_backward_in_two_launches_gives_the_one_launch_gradients(monkeypatch):
     torch.cuda.synchronize()
     for a, b, q in zip(two, one, _trunk_params(pol)):
         assert rel(a, b) < 1e-5, (tuple(q.shape), rel(a, b))
+
+
+def test_graph_captured_minibatches_give_the_eager_updates_parameters():
+    """PPOAgent(fused_update=True, graph_update=True): a full-size minibatch's forward + loss + backward is captured once in a HIP graph and
+    replayed (index_select into static inputs, one graph launch, then clip + Adam).  Same kernels in the same order as the eager direct
+    path, so after an update of 2 epochs x 4 minibatches (1 eager, 1 captured + replayed, 6 replayed) from the same rollout, the same
+    permutations and the same initial weights both agents hold the same parameters to f32 atomics' reassociation (db1 / dW2 / the conv
+    bias sums are atomically accumulated), and the same loss statistics."""
+    import torch
+    from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
+    n, T, bs = 128, 8, 256
+    torch.manual_seed(1)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    grid = (torch.rand(T, n, 12, 10, 15, device="cuda", generator=g) < 0.2)
+    from inversus_reinforcement_learning_amd import _lib as L
+    import ctypes as C
+    perms = [torch.randperm(n * T, generator=torch.Generator().manual_seed(7 + e)).numpy() for e in range(2)]
+    outs = []
+    for graph in (False, True):
+        pol = _policy(4)
+        agent = PPOAgent(pol, fused_act=True, fused_update=True, batch_size=bs, epochs=2, lr=1e-4, graph_update=graph)
+        assert agent.graph_update == graph and agent.direct_grads
+        gg = torch.Generator(device="cuda").manual_seed(3)
+        for t in range(T):
+            planes = grid[t].float()
+            extra = torch.rand(n, 4, device="cuda", generator=gg)
+            acts = torch.randint(0, 13, (n,), device="cuda", generator=gg)
+            lp = -2.5 + 0.1 * torch.randn(n, device="cuda", generator=gg)
+            val = 0.1 * torch.randn(n, device="cuda", generator=gg)
+            rew = 0.05 * torch.randn(n, device="cuda", generator=gg)
+            done = torch.rand(n, device="cuda", generator=gg) < 0.05
+            agent.store_batch(planes, extra, acts, lp, val, rew, done)
+        init = [p.detach().clone() for p in agent.policy.parameters()]
+        stats = agent.update(permutations=perms)
+        assert (agent._mb_graph is not None) == graph
+        outs.append((stats, init, [p.detach().clone() for p in agent.policy.parameters()]))
+    (s0, i0, p0), (s1, i1, p1) = outs
+    for k in ("policy_loss", "value_loss", "entropy"):
+        assert abs(s0[k] - s1[k]) < 1e-4 * max(1.0, abs(s0[k])), (k, s0[k], s1[k])
+    # The trunk's gradients end in f32 atomics (weight gradients, LayerNorm sums), so two EAGER updates differ in the last bits too, and
+    # Adam's normalised steps turn a last-bit difference of a near-zero gradient element into a difference of the step size: the bar
+    # is the parameter CHANGE per tensor, which must agree to a few per cent of its own norm (a skipped, doubled or mis-ordered minibatch
+    # changes it by tens of per cent).
+    for a0, a, b0, b in zip(i0, p0, i1, p1):
+        assert torch.equal(a0, b0)
+        da, db = (a - a0).double(), (b - b0).double()
+        assert float(da.norm()) > 0 and float((da - db).norm()) <= 0.05 * float(da.norm()) + 1e-12, (tuple(a.shape), float((da - db).norm() / da.norm()))
