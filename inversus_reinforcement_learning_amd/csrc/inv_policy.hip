@@ -978,7 +978,7 @@ __device__ __forceinline__ void bwd_request(BwdRegs<COUT> &rg, int bt, const voi
 // workgroup of the CU already fills that gap; removed.)
 template <int COUT, bool FROM_GLOBAL>
 __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf16 *xhat_n, float rstd, const bf16 *da_n, bf16 *dy_n, bf16 *dz_n,
-                                                 bf16 *tile, float *red, BwdRegs<COUT> &rg)
+                                                 bf16 *tile, float *red, BwdRegs<COUT> &rg, unsigned long long &stamp_prev, int layer)
 {
     // A thread owns the same NIT items (pixel, 8 channels) in both passes.  Pass A is a two-stage pipeline over batches of CH
     // items: the global loads of batch b + 1 (x^, LayerNorm parameters, and da for the top layer) are requested before batch b
@@ -1047,7 +1047,9 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
     float s2 = wave_sum(s2c[0] + s2c[1]);
     const int lane = tid & 63, wave = tid >> 6;
     if (lane == 0) { red[wave] = s1; red[WAVES + wave] = s2; }
+    STAMP(0 + layer);                                                // pass A (loads, dy, partial sums) of this wave
     __syncthreads();
+    STAMP(4 + layer);                                                // wait for the other waves' sums
     float S1 = 0.0f, S2 = 0.0f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) { S1 += red[w]; S2 += red[WAVES + w]; }
@@ -1069,13 +1071,15 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
             *reinterpret_cast<bf16x8 *>(tp) = dz;
         }
     }
+    STAMP(8 + layer);                                                // pass B (dz to HBM and into the tile)
     __syncthreads();                                 // dz tile complete (B operand of the transposed convolution); red[] reusable
+    STAMP(12 + layer);                                               // wait for the dz tile
 }
 
 // transposed conv of the dz tile -> da of the layer below, written back into the tile as bf16 (channels 0 .. COUT_BELOW)
 template <int CIN_T, int COUT_BELOW, int MW, int NW, bool RESIDUAL>
 __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int lane, int m0, int n0, BwdRegs<COUT_BELOW> &next, const void *next_ln,
-                                               const bf16 *next_xhat)
+                                               const bf16 *next_xhat, unsigned long long &stamp_prev, int layer)
 {
     f32x4 acc[MW][NW];
     const int c16 = lane & 15, kg = lane >> 4;
@@ -1098,7 +1102,9 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
 #else
     conv_gemm_rows<CIN_T, MW, NW, NW == H>(wt, tile, lane, m0, n0, acc);
 #endif
+    STAMP(16 + layer);                                               // transposed-convolution GEMM of this wave
     __syncthreads();                                 // every wave has finished reading the dz tile
+    STAMP(20 + layer);                                               // wait for the other waves' GEMMs
 #pragma unroll
     for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
@@ -1113,6 +1119,7 @@ __device__ __forceinline__ void conv_t_to_tile(const void *wt, bf16 *tile, int l
             }
         }
     __syncthreads();
+    STAMP(24 + layer);                                               // da into the tile + barrier
 }
 
 __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_params prm, inv_policy_saved sv, const bf16 *__restrict__ dfeat,
@@ -1129,6 +1136,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         reinterpret_cast<bf16x8 *>(&tile[0])[i] = z;
     }
     __syncthreads();
+    unsigned long long stamp_prev = 0;                               // (diagnostic builds: tools/bwd_stamps.py)
+    STAMP_INIT();
+#ifdef INV_POLICY_STAMPS
+    stamp_prev = stamp_now();
+#endif
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         int lane_i = lane;
         asm volatile("" : "+v"(lane_i));
@@ -1140,17 +1152,18 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         BwdRegs<64> rb;
         BwdRegs<32> rc;
         ln_relu_bwd_rows<128, true>(prm.ln[3], xh3, rs.w, dfeat + sn * 128, reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128,
-                                    reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red, ra);
-        conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0, ra, prm.ln[2], xh2);
+                                    reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red, ra, stamp_prev, 3);
+        conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0, ra, prm.ln[2], xh2, stamp_prev, 3);
         ln_relu_bwd_rows<128, false>(prm.ln[2], xh2, rs.z, nullptr, reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128,
-                                            reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128, tile, red, ra);
-        conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0, rb, prm.ln[1], xh1);
+                                            reinterpret_cast<bf16 *>(gr.dz[2]) + sn * 128, tile, red, ra, stamp_prev, 2);
+        conv_t_to_tile<128, 64, 1, 10, false>(prm.wt[1], tile, lane_i, wave, 0, rb, prm.ln[1], xh1, stamp_prev, 2);
         ln_relu_bwd_rows<64, false>(prm.ln[1], xh1, rs.y, nullptr, reinterpret_cast<bf16 *>(gr.dy[1]) + sn * 64,
-                                           reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64, tile, red, rb);
-        conv_t_to_tile<64, 32, 1, 5, false>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5, rc, prm.ln[0], xh0);
+                                           reinterpret_cast<bf16 *>(gr.dz[1]) + sn * 64, tile, red, rb, stamp_prev, 1);
+        conv_t_to_tile<64, 32, 1, 5, false>(prm.wt[0], tile, lane_i, wave & 1, (wave >> 1) * 5, rc, prm.ln[0], xh0, stamp_prev, 1);
         ln_relu_bwd_rows<32, false>(prm.ln[0], xh0, rs.x, nullptr, reinterpret_cast<bf16 *>(gr.dy[0]) + sn * 32,
-                                           reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32, tile, red, rc);
+                                           reinterpret_cast<bf16 *>(gr.dz[0]) + sn * 32, tile, red, rc, stamp_prev, 0);
     }
+    STAMP_FLUSH();
 }
 
 
