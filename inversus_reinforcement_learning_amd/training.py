@@ -149,6 +149,11 @@ class RolloutCollector:
             if self.opponent_actions is not None:
                 del self.opponent_actions[n_opp:]
         else:
+            # an eager rollout in between (another length) left the current observations in fresh tensors: the graph starts from the static ones
+            cur = list(self.obs) + (list(self.obs_p2) if self.selfplay else [])
+            for dst, src in zip(st["static"], cur):
+                if dst is not src:
+                    dst.copy_(src)
             for name in self._AGENT_BUFFERS:
                 setattr(agent, name, list(st["buffers"][name]))
             self._pending = list(st["pending"])

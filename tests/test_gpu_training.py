@@ -343,3 +343,8 @@ def test_graph_collector_refuses_what_it_cannot_capture():
     agent.reset_buffers()
     col.collect(5)                                                                           # another length: eager
     assert len(agent.obs_grid_buffer) == 5 and col._graph_state["steps"] == 3
+    # ... and a replay after that eager rollout starts from the eager rollout's LAST observation, not from a stale static buffer
+    last = col.obs[0].clone()
+    agent.reset_buffers()
+    col.collect(3)
+    assert torch.equal(agent.obs_grid_buffer[0], last)
