@@ -298,25 +298,26 @@ def test_backward_in_two_launches_gives_the_one_launch_gradients(monkeypatch):
         assert rel(a, b) < 1e-5, (tuple(q.shape), rel(a, b))
 
 
-def test_graph_captured_minibatches_give_the_eager_updates_parameters():
+def test_graph_captured_minibatches_give_the_eager_minibatches_gradients():
     """PPOAgent(fused_update=True, graph_update=True): a full-size minibatch's forward + loss + backward is captured once in a HIP graph and
-    replayed (index_select into static inputs, one graph launch, then clip + Adam).  Same kernels in the same order as the eager direct
-    path, so after an update of 2 epochs x 4 minibatches (1 eager, 1 captured + replayed, 6 replayed) from the same rollout, the same
-    permutations and the same initial weights both agents hold the same parameters to f32 atomics' reassociation (db1 / dW2 / the conv
-    bias sums are atomically accumulated), and the same loss statistics."""
+    replayed (index_select into static inputs, one graph launch, then clip + Adam outside the graph).  With lr = 0 the parameters never
+    move, so every minibatch of an update is evaluated at the same weights in both agents: after 2 epochs x 4 minibatches (1 eager,
+    1 captured + replayed, 6 replayed) from the same rollout and the same permutations, the flat gradient bucket (= the LAST minibatch's
+    gradients, written by a REPLAY in one agent and eagerly in the other) agrees to the f32 atomics' reassociation, the loss statistics
+    averaged over all eight minibatches agree, and both optimizers have stepped eight times.  (Comparing parameters after real Adam steps
+    is not a test of the graph: the first Adam steps are sign-like, so a last-bit difference of a near-zero gradient element -- which two
+    EAGER runs have as well -- becomes a difference of the step size.)"""
     import torch
     from inversus_reinforcement_learning_amd.ppo_agent import PPOAgent
     n, T, bs = 128, 8, 256
     torch.manual_seed(1)
     g = torch.Generator(device="cuda").manual_seed(2)
     grid = (torch.rand(T, n, 12, 10, 15, device="cuda", generator=g) < 0.2)
-    from inversus_reinforcement_learning_amd import _lib as L
-    import ctypes as C
     perms = [torch.randperm(n * T, generator=torch.Generator().manual_seed(7 + e)).numpy() for e in range(2)]
     outs = []
     for graph in (False, True):
         pol = _policy(4)
-        agent = PPOAgent(pol, fused_act=True, fused_update=True, batch_size=bs, epochs=2, lr=1e-4, graph_update=graph)
+        agent = PPOAgent(pol, fused_act=True, fused_update=True, batch_size=bs, epochs=2, lr=0.0, graph_update=graph)
         assert agent.graph_update == graph and agent.direct_grads
         gg = torch.Generator(device="cuda").manual_seed(3)
         for t in range(T):
@@ -330,16 +331,12 @@ def test_graph_captured_minibatches_give_the_eager_updates_parameters():
             agent.store_batch(planes, extra, acts, lp, val, rew, done)
         init = [p.detach().clone() for p in agent.policy.parameters()]
         stats = agent.update(permutations=perms)
-        assert (agent._mb_graph is not None) == graph
-        outs.append((stats, init, [p.detach().clone() for p in agent.policy.parameters()]))
-    (s0, i0, p0), (s1, i1, p1) = outs
+        assert (agent._mb_graph is not None) == graph and agent.flat_adam.steps == 8
+        assert all(torch.equal(a, b.detach()) for a, b in zip(init, agent.policy.parameters()))           # lr = 0
+        outs.append((stats, agent.flat_adam.grad.detach().clone(), [p.grad.detach().clone() for p in agent.policy.parameters()]))
+    (s0, f0, g0), (s1, f1, g1) = outs
     for k in ("policy_loss", "value_loss", "entropy"):
-        assert abs(s0[k] - s1[k]) < 1e-4 * max(1.0, abs(s0[k])), (k, s0[k], s1[k])
-    # The trunk's gradients end in f32 atomics (weight gradients, LayerNorm sums), so two EAGER updates differ in the last bits too, and
-    # Adam's normalised steps turn a last-bit difference of a near-zero gradient element into a difference of the step size: the bar
-    # is the parameter CHANGE per tensor, which must agree to a few per cent of its own norm (a skipped, doubled or mis-ordered minibatch
-    # changes it by tens of per cent).
-    for a0, a, b0, b in zip(i0, p0, i1, p1):
-        assert torch.equal(a0, b0)
-        da, db = (a - a0).double(), (b - b0).double()
-        assert float(da.norm()) > 0 and float((da - db).norm()) <= 0.05 * float(da.norm()) + 1e-12, (tuple(a.shape), float((da - db).norm() / da.norm()))
+        assert abs(s0[k] - s1[k]) < 1e-5 * max(1.0, abs(s0[k])), (k, s0[k], s1[k])
+    assert float(f0.norm()) > 0
+    for a, b in zip(g0, g1):
+        assert float((a.double() - b.double()).norm()) <= 1e-4 * float(a.double().norm()) + 1e-9, (tuple(a.shape), float((a - b).norm() / a.norm()))
