@@ -594,53 +594,63 @@ __device__ __forceinline__ bf16x8 ln_relu8(const bf16x8 z, const f16x8 l0, const
     return o;
 }
 
-// layers 2..4: tile <- relu(LN(z_prev)) for the band's R + 2 rows, zeros outside the board
-template <class G, int R, int CPREV>
-__device__ __forceinline__ void band_load_norm(bf16 *tile, const bf16 *__restrict__ zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band)
+// layers 2..4: tile <- relu(LN(z_prev)) for the band's R + 2 rows, zeros outside the board.
+// band_rows_norm builds tile rows [ROW0, ROW0 + NROWS) from global memory -- board columns only: the halo columns and the guard
+// position are zero from the kernel's start and nothing below writes them -- and the NROWS board rows are ONE contiguous piece of the
+// channels-last tensor, so item q of the pass is the q-th 16-byte chunk of that piece.  `carry`: the band's rows 0, 1 are the
+// previous band's rows R, R + 1, already normalised in the tile (band_conv stages its output in rows 0 .. R - 1 and leaves them
+// alone); each thread moves the old contents of the position it is about to overwrite up by R rows first, so no barrier is needed
+// and a band fetches R rows instead of R + 2 (8 bands of a 32-row board: 34 instead of 48 rows of z and of LayerNorm parameters).
+template <class G, int R, int CPREV, int ROW0, int NROWS>
+__device__ __forceinline__ void band_rows_norm(bf16 *tile, const bf16 *__restrict__ zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band, bool carry)
 {
-    constexpr int C8 = CPREV / 8, ITEMS = G::TR * G::PWB * C8, NIT = (ITEMS + THREADS - 1) / THREADS, CH = NIT < 7 ? NIT : 7;
+    constexpr int WBc = G::PWB - 2, HBc = G::P / WBc, C8 = CPREV / 8, ROWI = WBc * C8, ITEMS = NROWS * ROWI, NIT = ITEMS / THREADS;
+    static_assert(ITEMS % THREADS == 0 && NIT <= 8 && ((R - ROW0) * ROWI) % THREADS == 0, "whole passes; an item is carried or not by its index alone");
     // The item coordinates depend on the thread id only: hipcc hoists them out of the band loop and keeps ~4 registers per
     // item live across the GEMM, which then spills its weight pointers (scratch_load + s_waitcnt vmcnt(0) in every k-step).
     // Laundering the id makes them cheap per-band recomputations.
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-#pragma unroll 1
-    for (int k0 = 0; k0 < NIT; k0 += CH) {
-        bf16x8 z[CH];
-        f16x8 l0[CH], l1[CH];
-        int dsto[CH];
-        bool in[CH];
+    const int y0 = band * R + ROW0 - 1;
+    bf16x8 z[NIT], old[NIT];
+    f16x8 l0[NIT], l1[NIT];
+    int dsto[NIT];
+    bool in[NIT];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int q = tid + (k0 + j) * THREADS;
-            const int pos = q / C8, part = q - pos * C8, tr = pos / G::PWB, tc = pos - tr * G::PWB;
-            const int y = band * R + tr - 1, x = tc - 1;
-            in[j] = q < ITEMS && (unsigned)y < (unsigned)(G::P / (G::PWB - 2)) && (unsigned)x < (unsigned)(G::PWB - 2);
-            dsto[j] = q < ITEMS ? pos * CSF + part * 8 : -1;
-            const int p = in[j] ? y * (G::PWB - 2) + x : 0;
-            const size_t o = (size_t)p * CPREV + part * 8;
-            if (POL_BAND_KNOCK & 4) {
+    for (int j = 0; j < NIT; ++j) {
+        const int q = tid + j * THREADS;
+        const int rr = q / ROWI, rem = q - rr * ROWI, x = rem / C8, part = rem - x * C8;
+        in[j] = (unsigned)(y0 + rr) < (unsigned)HBc;
+        dsto[j] = ((ROW0 + rr) * G::PWB + x + 1) * CSF + part * 8;
+        if (ROW0 + (j * THREADS) / ROWI >= R && carry) old[j] = *reinterpret_cast<const bf16x8 *>(tile + dsto[j]);
+        const size_t o = in[j] ? ((size_t)(y0 + rr) * ROWI + rem) * 8 : 0;
+        if (POL_BAND_KNOCK & 4) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { z[j][e] = (bf16)(float)(o & 3); l0[j][e] = (_Float16)1.0f; l1[j][e] = (_Float16)0.5f; }
-                continue;
-            }
-            z[j] = *reinterpret_cast<const bf16x8 *>(zprev + o);
-            const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_prev) + o * 2;
-            l0[j] = *reinterpret_cast<const f16x8 *>(lq);
-            l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+            for (int e = 0; e < 8; ++e) { z[j][e] = (bf16)(float)(o & 3); l0[j][e] = (_Float16)1.0f; l1[j][e] = (_Float16)0.5f; }
+            continue;
         }
-        POL_PIN();
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (dsto[j] >= 0) {
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)0.0f;
-                if (in[j]) o = ln_relu8(z[j], l0[j], l1[j], rstd, shift);
-                *reinterpret_cast<bf16x8 *>(tile + dsto[j]) = o;
-            }
-        }
+        z[j] = *reinterpret_cast<const bf16x8 *>(zprev + o);
+        const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln_prev) + o * 2;
+        l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+        l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
     }
+    POL_PIN();
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        if (ROW0 + (j * THREADS) / ROWI >= R && carry) *reinterpret_cast<bf16x8 *>(tile + dsto[j] - R * G::PWB * CSF) = old[j];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)0.0f;
+        if (in[j]) o = ln_relu8(z[j], l0[j], l1[j], rstd, shift);
+        *reinterpret_cast<bf16x8 *>(tile + dsto[j]) = o;
+    }
+}
+
+template <class G, int R, int CPREV>
+__device__ __forceinline__ void band_load_norm(bf16 *tile, const bf16 *__restrict__ zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band)
+{
+    if (band == 0) band_rows_norm<G, R, CPREV, 0, 2>(tile, zprev, ln_prev, rstd, shift, band, false);
+    band_rows_norm<G, R, CPREV, 2, R>(tile, zprev, ln_prev, rstd, shift, band, band > 0);
 }
 
 // layer 1: tile <- the observation's 12 planes (+ 20 zero channels) for the band's R + 2 rows
@@ -773,7 +783,7 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16)acc[mi][i][e];
-            *reinterpret_cast<bf16x4 *>(tile + base[i] + ch0) = o;
+            *reinterpret_cast<bf16x4 *>(tile + base[i] - G::PWB * CSF + ch0) = o;   // staged one row up: rows R, R + 1 stay the next band's rows 0, 1
         }
     }
     __syncthreads();
@@ -783,7 +793,7 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
     asm volatile("" : "+v"(tid1));
     for (int q = tid1; q < R * WBc * C8; q += THREADS) {             // whole rows: consecutive threads, consecutive 16-B chunks
         const int pb = q / C8, part = q - pb * C8, rr = pb / WBc, x = pb - rr * WBc;
-        if (!(POL_BAND_KNOCK & 8)) dst[q] = *reinterpret_cast<const bf16x8 *>(tile + ((rr + 1) * G::PWB + x + 1) * CSF + part * 8);
+        if (!(POL_BAND_KNOCK & 8)) dst[q] = *reinterpret_cast<const bf16x8 *>(tile + (rr * G::PWB + x + 1) * CSF + part * 8);
     }
     __syncthreads();                                                 // the tile is rebuilt by the next band
     STAMP(slot0 + 3);                                                // z through the tile to global memory
@@ -1795,36 +1805,44 @@ __global__ __launch_bounds__(256) void k_band_ln_bwd2(const bf16 *__restrict__ d
     *reinterpret_cast<float4 *>(o + stride + 4) = make_float4(ab[4], ab[5], ab[6], ab[7]);
 }
 
-// raw band loader: tile <- the band's R + 2 rows of a channels-last tensor [P][CSRC], zeros outside the board
+// raw band loader: tile <- the band's R + 2 rows of a channels-last tensor [P][CSRC], zeros outside the board; rows carried over
+// from the previous band like band_rows_norm's
+template <class G, int R, int CSRC, int ROW0, int NROWS>
+__device__ __forceinline__ void band_rows_raw(bf16 *tile, const bf16 *__restrict__ src, int band, bool carry)
+{
+    constexpr int WBc = G::PWB - 2, HBc = G::P / WBc, C8 = CSRC / 8, ROWI = WBc * C8, ITEMS = NROWS * ROWI, NIT = ITEMS / THREADS;
+    static_assert(ITEMS % THREADS == 0 && NIT <= 8 && ((R - ROW0) * ROWI) % THREADS == 0, "whole passes; an item is carried or not by its index alone");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int y0 = band * R + ROW0 - 1;
+    bf16x8 v[NIT], old[NIT];
+    int dsto[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int q = tid + j * THREADS;
+        const int rr = q / ROWI, rem = q - rr * ROWI, x = rem / C8, part = rem - x * C8;
+        const bool in = (unsigned)(y0 + rr) < (unsigned)HBc;
+        dsto[j] = ((ROW0 + rr) * G::PWB + x + 1) * CSF + part * 8;
+        if (ROW0 + (j * THREADS) / ROWI >= R && carry) old[j] = *reinterpret_cast<const bf16x8 *>(tile + dsto[j]);
+        v[j] = *reinterpret_cast<const bf16x8 *>(src + (in ? ((size_t)(y0 + rr) * ROWI + rem) * 8 : 0));
+        if (!in) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = (bf16)0.0f;
+        }
+    }
+    POL_PIN();
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        if (ROW0 + (j * THREADS) / ROWI >= R && carry) *reinterpret_cast<bf16x8 *>(tile + dsto[j] - R * G::PWB * CSF) = old[j];
+        *reinterpret_cast<bf16x8 *>(tile + dsto[j]) = v[j];
+    }
+}
+
 template <class G, int R, int CSRC>
 __device__ __forceinline__ void band_load_raw(bf16 *tile, const bf16 *__restrict__ src, int band)
 {
-    constexpr int C8 = CSRC / 8, ITEMS = G::TR * G::PWB * C8, NIT = (ITEMS + THREADS - 1) / THREADS, CH = NIT < 8 ? NIT : 8;
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-#pragma unroll 1
-    for (int k0 = 0; k0 < NIT; k0 += CH) {
-        bf16x8 v[CH];
-        int dsto[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int q = tid + (k0 + j) * THREADS;
-            const int pos = q / C8, part = q - pos * C8, tr = pos / G::PWB, tc = pos - tr * G::PWB;
-            const int y = band * R + tr - 1, x = tc - 1;
-            const bool in = q < ITEMS && (unsigned)y < (unsigned)(G::P / (G::PWB - 2)) && (unsigned)x < (unsigned)(G::PWB - 2);
-            dsto[j] = q < ITEMS ? pos * CSF + part * 8 : -1;
-            const int p = in ? y * (G::PWB - 2) + x : 0;
-            v[j] = *reinterpret_cast<const bf16x8 *>(src + (size_t)p * CSRC + part * 8);
-            if (!in) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[j][e] = (bf16)0.0f;
-            }
-        }
-        POL_PIN();
-#pragma unroll
-        for (int j = 0; j < CH; ++j)
-            if (dsto[j] >= 0) *reinterpret_cast<bf16x8 *>(tile + dsto[j]) = v[j];
-    }
+    if (band == 0) band_rows_raw<G, R, CSRC, 0, 2>(tile, src, band, false);
+    band_rows_raw<G, R, CSRC, 2, R>(tile, src, band, band > 0);
 }
 
 // da_below[n] = convT(dz[n]) (+ dz[n]: RESIDUAL, the skip connection around conv4).  lp.w: the transposed packing of the layer's
