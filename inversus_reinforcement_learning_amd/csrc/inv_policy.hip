@@ -563,8 +563,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk(inv_policy_params p
 // Board-generic trunk for boards whose activations do not fit LDS ("banded"; SURVEY.md 8f row N1 for BASELINE config C5:
 // 32 x 32 is 262 KB of bf16 activations per layer and sample).  Per sample and layer the board is processed in BANDS of R
 // rows: the band's input (R + 2 rows with halo) is built in the LDS tile -- layer 1 from the observation, later layers from the
-// previous layer's PRE-norm output z (bf16 channels-last in a per-workgroup scratch: 2 x 262 KB per workgroup, 268 MB for the
-// 2 x 256 resident workgroups -- as large as the whole Infinity Cache, so it is cache-assisted L2 / HBM traffic, not resident;
+// previous layer's PRE-norm output z (bf16 channels-last in a per-workgroup scratch: 262 KB per workgroup, 134 MB for the
+// 2 x 256 resident workgroups -- half the Infinity Cache; until round 5 two ping-pong buffers, 268 MB;
 // the host side keeps ONE scratch per device and stream for all policies, fused_policy.py) with
 // LayerNorm + affine + ReLU applied on the way in, which is possible because a layer's statistics are complete before the
 // next layer starts -- then the same implicit GEMM as above runs on the band (tiles of 16 pixels = pieces of board rows: no
@@ -602,7 +602,7 @@ __device__ __forceinline__ bf16x8 ln_relu8(const bf16x8 z, const f16x8 l0, const
 // alone); each thread moves the old contents of the position it is about to overwrite up by R rows first, so no barrier is needed
 // and a band fetches R rows instead of R + 2 (8 bands of a 32-row board: 34 instead of 48 rows of z and of LayerNorm parameters).
 template <class G, int R, int CPREV, int ROW0, int NROWS>
-__device__ __forceinline__ void band_rows_norm(bf16 *tile, const bf16 *__restrict__ zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band, bool carry)
+__device__ __forceinline__ void band_rows_norm(bf16 *tile, const bf16 *zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band, bool carry)
 {
     constexpr int WBc = G::PWB - 2, HBc = G::P / WBc, C8 = CPREV / 8, ROWI = WBc * C8, ITEMS = NROWS * ROWI, NIT = ITEMS / THREADS;
     static_assert(ITEMS % THREADS == 0 && NIT <= 8 && ((R - ROW0) * ROWI) % THREADS == 0, "whole passes; an item is carried or not by its index alone");
@@ -647,7 +647,7 @@ __device__ __forceinline__ void band_rows_norm(bf16 *tile, const bf16 *__restric
 }
 
 template <class G, int R, int CPREV>
-__device__ __forceinline__ void band_load_norm(bf16 *tile, const bf16 *__restrict__ zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band)
+__device__ __forceinline__ void band_load_norm(bf16 *tile, const bf16 *zprev, const void *__restrict__ ln_prev, float rstd, float shift, int band)
 {
     if (band == 0) band_rows_norm<G, R, CPREV, 0, 2>(tile, zprev, ln_prev, rstd, shift, band, false);
     band_rows_norm<G, R, CPREV, 2, R>(tile, zprev, ln_prev, rstd, shift, band, band > 0);
@@ -738,7 +738,7 @@ __device__ __forceinline__ void band_gemm_rows(const void *w, const bf16 *tile, 
 
 // conv3x3 on the band + bias (+ residual), statistics, z (bf16) back to the scratch through the tile
 template <class G, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL>
-__device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile, bf16 *__restrict__ zout, int band, int lane, int m0, int n0, float &s, float &ss,
+__device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile, bf16 *zout, int band, int lane, int m0, int n0, float &s, float &ss,
                                           unsigned long long &stamp_prev, int slot0 = 0)
 {
     asm volatile("" : "+v"(lane));
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
     __shared__ uint32_t obw[BITS ? G::OWB : 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
-    bf16 *const zA0 = SAVE ? nullptr : scratch + (size_t)blockIdx.x * 2 * G::P * 128, *const zB0 = SAVE ? nullptr : zA0 + (size_t)G::P * 128;
+    bf16 *const zW = SAVE ? nullptr : scratch + (size_t)blockIdx.x * G::P * 128;
     for (int i = tid; i < G::NPOSB * CSF / 8; i += THREADS) {
         bf16x8 z;
 #pragma unroll
@@ -846,11 +846,16 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
             for (int w = tid; w < G::OWB; w += THREADS) obw[BITS ? w : 0] = reinterpret_cast<const uint32_t *>(obs_in)[(size_t)n * G::OWB + w];
             __syncthreads();
         }
-        // where the four layers' z live: two ping-pong scratch buffers, or (SAVE) this sample's slices of the saved tensors
-        bf16 *const z1 = SAVE ? reinterpret_cast<bf16 *>(sv.z[0]) + (size_t)n * G::P * 32 : zA0;
-        bf16 *const z2 = SAVE ? reinterpret_cast<bf16 *>(sv.z[1]) + (size_t)n * G::P * 64 : zB0;
-        bf16 *const z3 = SAVE ? reinterpret_cast<bf16 *>(sv.z[2]) + (size_t)n * G::P * 128 : zA0;
-        bf16 *const z4 = SAVE ? reinterpret_cast<bf16 *>(sv.z[3]) + (size_t)n * G::P * 128 : zB0;
+        // where the four layers' z live: (SAVE) this sample's slices of the saved tensors, or ONE [P][128] scratch per workgroup in
+        // which every layer's z ENDS at the end of the buffer (z_l at element P * (128 - C_l)).  A layer may overwrite its own input
+        // there: band b has fetched the input's board rows up to R b + R before it stores output rows R b .. R b + R - 1 (the rows
+        // after that come from the tile, band_rows_norm), and an output row of C' channels that starts P (C' - C) elements before
+        // the input's ends at or before the first unread input row: HB (C' - C) + (R b + R + 1) C >= (R b + R) C' since R b + R <= HB.
+        // Half the footprint of two ping-pong buffers (134 MB for 512 workgroups: inside the 256-MB Infinity Cache).
+        bf16 *const z1 = SAVE ? reinterpret_cast<bf16 *>(sv.z[0]) + (size_t)n * G::P * 32 : zW + (size_t)G::P * 96;
+        bf16 *const z2 = SAVE ? reinterpret_cast<bf16 *>(sv.z[1]) + (size_t)n * G::P * 64 : zW + (size_t)G::P * 64;
+        bf16 *const z3 = SAVE ? reinterpret_cast<bf16 *>(sv.z[2]) + (size_t)n * G::P * 128 : zW;
+        bf16 *const z4 = SAVE ? reinterpret_cast<bf16 *>(sv.z[3]) + (size_t)n * G::P * 128 : zW;
         float s, ss, rstd, shift;
 #ifdef INV_POLICY_STAMPS
         unsigned long long stamp_prev = stamp_now();                  // phase shares: tools/banded_stamps.py
@@ -2065,7 +2070,7 @@ static int launch_trunk(const inv_policy_params *params, const void *obs, bool b
 extern "C" int64_t inv_policy_trunk_banded_scratch_bytes(int32_t height, int32_t width)
 {
     if (height != 32 || width != 32) return 0;
-    return (int64_t)2 * inv_cu_count() * 2 * (int64_t)height * width * 128 * 2;          // 2 workgroups per CU, two [P][128] bf16 buffers each
+    return (int64_t)2 * inv_cu_count() * (int64_t)height * width * 128 * 2;              // 2 workgroups per CU, one [P][128] bf16 buffer each
 }
 
 extern "C" int inv_policy_trunk_banded(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, int32_t height, int32_t width,

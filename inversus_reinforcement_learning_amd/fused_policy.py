@@ -138,9 +138,9 @@ class FusedPolicy:
         self.b1 = torch.cat([m.bias for m in firsts]).detach().float()
         self.hidden = p.fc_actor[0].out_features
 
-    # The banded kernel's per-workgroup z scratch (268 MB on a 256-CU part).  It is only live inside one launch, and launches of
+    # The banded kernel's per-workgroup z scratch (134 MB on a 256-CU part).  It is only live inside one launch, and launches of
     # one stream run one after the other, so every policy on a (device, stream) pair shares ONE buffer (the learner and the frozen
-    # self-play opponent used to hold one each: 0.5 GB).
+    # self-play opponent used to hold one each).
     _banded_scratch = {}
 
     @classmethod
