@@ -653,33 +653,49 @@ __device__ __forceinline__ void band_load_norm(bf16 *tile, const bf16 *zprev, co
     band_rows_norm<G, R, CPREV, 2, R>(tile, zprev, ln_prev, rstd, shift, band, band > 0);
 }
 
-// layer 1: tile <- the observation's 12 planes (+ 20 zero channels) for the band's R + 2 rows
+// layer 1: tile <- the observation's 12 planes (+ 20 zero channels) for the band's R + 2 rows, built and carried over like
+// band_rows_norm's rows.  Item = (16-byte chunk of 8 channels, position): chunks 0 and 1 hold the planes, 2 and 3 are zeros, and a
+// wave's 64 items share their chunk (NP is a multiple of 64), so the branch on it is uniform.
+template <class G, int R, bool BITS, int ROW0, int NROWS>
+__device__ __forceinline__ void band_rows_obs(bf16 *tile, const uint32_t *obw, const float *__restrict__ planes, int band, bool carry)
+{
+    constexpr int WBc = G::PWB - 2, HBc = G::P / WBc, NP = NROWS * WBc, ITEMS = 4 * NP, NIT = ITEMS / THREADS;
+    static_assert(ITEMS % THREADS == 0 && NP % 64 == 0, "whole passes, one chunk per wave");
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int y0 = band * R + ROW0 - 1;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int q = tid + j * THREADS, part = q / NP, pos = q - part * NP, rr = pos / WBc, x = pos - rr * WBc, y = y0 + rr;
+        bf16 *dst = tile + ((ROW0 + rr) * G::PWB + x + 1) * CSF + part * 8;
+        if (carry && ROW0 + rr >= R) *reinterpret_cast<bf16x8 *>(dst - R * G::PWB * CSF) = *reinterpret_cast<const bf16x8 *>(dst);
+        uint32_t w[4] = { 0u, 0u, 0u, 0u };
+        if (part < 2 && (unsigned)y < (unsigned)HBc) {
+            const int p = y * WBc + x;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = part * 8 + e;
+                uint32_t h = 0u;
+                if (c < 12) {
+                    if (BITS) {
+                        const int bi = c * G::P + p;
+                        h = ((obw[bi >> 5] >> (bi & 31)) & 1u) * 0x3F80u;
+                    } else {
+                        h = __builtin_bit_cast(unsigned short, (bf16)planes[(size_t)c * G::P + p]);
+                    }
+                }
+                w[e >> 1] |= h << (16 * (e & 1));
+            }
+        }
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 template <class G, int R, bool BITS>
 __device__ __forceinline__ void band_load_obs(bf16 *tile, const uint32_t *obw, const float *__restrict__ planes, int band)
 {
-    constexpr int WBc = G::PWB - 2, HBc = G::P / WBc;
-    int tid0 = threadIdx.x;
-    asm volatile("" : "+v"(tid0));
-    for (int z = tid0; z < G::TR * G::PWB * 8; z += THREADS) {              // one 8-byte quad (4 channels) per item
-        const int pos = z >> 3, part = z & 7, tr = pos / G::PWB, tc = pos - tr * G::PWB;
-        const int y = band * R + tr - 1, x = tc - 1;
-        uint32_t lo = 0u, hi = 0u;
-        if (part < 3 && (unsigned)y < (unsigned)HBc && (unsigned)x < (unsigned)WBc) {
-            const int p = y * WBc + x;
-            if (BITS) {
-                const int b0 = (4 * part) * G::P + p, b1 = b0 + G::P, b2 = b1 + G::P, b3 = b2 + G::P;
-                lo = (((obw[b0 >> 5] >> (b0 & 31)) & 1u) * 0x3F80u) | (((obw[b1 >> 5] >> (b1 & 31)) & 1u) * 0x3F800000u);
-                hi = (((obw[b2 >> 5] >> (b2 & 31)) & 1u) * 0x3F80u) | (((obw[b3 >> 5] >> (b3 & 31)) & 1u) * 0x3F800000u);
-            } else {
-                bf16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (bf16)planes[(size_t)(4 * part + e) * G::P + p];
-                const uint2 u = __builtin_bit_cast(uint2, v);
-                lo = u.x; hi = u.y;
-            }
-        }
-        *reinterpret_cast<uint2 *>(tile + pos * CSF + part * 4) = make_uint2(lo, hi);
-    }
+    if (band == 0) band_rows_obs<G, R, BITS, 0, 2>(tile, obw, planes, band, false);
+    band_rows_obs<G, R, BITS, 2, R>(tile, obw, planes, band, band > 0);
 }
 
 
@@ -791,10 +807,17 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
     bf16x8 *dst = reinterpret_cast<bf16x8 *>(zout + (size_t)band * R * WBc * COUT);
     int tid1 = threadIdx.x;
     asm volatile("" : "+v"(tid1));
-    for (int q = tid1; q < R * WBc * C8; q += THREADS) {             // whole rows: consecutive threads, consecutive 16-B chunks
-        const int pb = q / C8, part = q - pb * C8, rr = pb / WBc, x = pb - rr * WBc;
-        if (!(POL_BAND_KNOCK & 8)) dst[q] = *reinterpret_cast<const bf16x8 *>(tile + (rr * G::PWB + x + 1) * CSF + part * 8);
+    constexpr int NOUT = R * WBc * C8 / THREADS;
+    static_assert((R * WBc * C8) % THREADS == 0, "whole passes");
+    bf16x8 zo[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {                                 // whole rows: consecutive threads, consecutive 16-B chunks
+        const int q = tid1 + j * THREADS, pb = q / C8, part = q - pb * C8, rr = pb / WBc, x = pb - rr * WBc;
+        zo[j] = *reinterpret_cast<const bf16x8 *>(tile + (rr * G::PWB + x + 1) * CSF + part * 8);
     }
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j)
+        if (!(POL_BAND_KNOCK & 8)) dst[tid1 + j * THREADS] = zo[j];
     __syncthreads();                                                 // the tile is rebuilt by the next band
     STAMP(slot0 + 3);                                                // z through the tile to global memory
 }
@@ -908,7 +931,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 6] = rstd; sv.stats[(size_t)n * 8 + 7] = shift; }
         // features: relu(LN4(z4)), channels-last [P][128]
         if (!(POL_BAND_KNOCK & 32)) {
-            constexpr int ITEMS = G::P * 16, CH = 4;
+            constexpr int ITEMS = G::P * 16, CH = 8;                 // a pass per memory round trip: 8 items in flight halve the passes of 4
             bf16x8 *dst = reinterpret_cast<bf16x8 *>(feat + (size_t)n * G::P * 128);
 #pragma unroll 1
             for (int q0 = tid; q0 < ITEMS; q0 += CH * THREADS) {
