@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define INV_ABI_VERSION 6
+#define INV_ABI_VERSION 7
 
 typedef enum {
     INV_OK = 0,
@@ -257,6 +257,13 @@ int  inv_policy_band_ln_bwd2(int32_t layer, int32_t height, int32_t width, const
                              int32_t N, void *stream);
 int  inv_policy_band_conv_t(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,
                             const void *dz_bf16, void *da_below_bf16, int32_t N, void *stream);
+/* ABI 7: inv_policy_band_conv_t(l) that also leaves, per sample, the two LayerNorm-backward sums of layer l - 1 (sums_below f32 [N][2],
+ * what inv_policy_band_ln_sums(l - 1) computes from da_{l-1}: here from the chunks of da_{l-1} as they are written, z_{l-1}, stats and
+ * layer l - 1's packed LayerNorm parameters; same expressions, another order of the f32 additions) -- one read of da_{l-1} and one
+ * launch less per layer (fused_train.py's banded backward; INVERSUS_BAND_FUSED_SUMS=0 keeps the separate pass). */
+int  inv_policy_band_conv_t_sums(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,
+                                 const void *dz_bf16, void *da_below_bf16, const void *z_below_bf16, const float *stats,
+                                 const void *ln_below_packed, float *sums_below, int32_t N, void *stream);
 int  inv_policy_band_act(int32_t layer, int32_t height, int32_t width, const void *z_bf16, const float *stats, const void *ln_packed,
                          void *act_bf16, int32_t N, void *stream);
 int  inv_policy_band_wgrad(int32_t layer, int32_t height, int32_t width, const void *x_bf16, const void *dz_bf16, float *dw, float *dbias,

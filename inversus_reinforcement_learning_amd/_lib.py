@@ -139,6 +139,7 @@ SIGNATURES = {
     "inv_policy_band_ln_sums": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_band_ln_bwd2": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, _V]),
     "inv_policy_band_conv_t": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
+    "inv_policy_band_conv_t_sums": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_band_act": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_band_wgrad": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_band_param_grads": (C.c_int, [C.c_int32, _V, _V, _V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V]),

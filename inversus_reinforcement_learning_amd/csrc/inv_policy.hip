@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/inversus_hip.h"
 #include "inv_internal.h"
@@ -753,9 +754,14 @@ __device__ __forceinline__ void band_gemm_rows(const void *w, const bf16 *tile, 
 }
 
 // conv3x3 on the band + bias (+ residual), statistics, z (bf16) back to the scratch through the tile
-template <class G, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL>
+// WB: a hook on the write-back pass (k_band_conv_t's LayerNorm sums); items() sees the NOUT chunks a thread writes, as written.
+struct NoWriteBackHook {
+    template <int NOUT> __device__ __forceinline__ void items(int, int, const bf16x8 (&)[NOUT]) {}
+};
+
+template <class G, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL, class WB = NoWriteBackHook>
 __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile, bf16 *zout, int band, int lane, int m0, int n0, float &s, float &ss,
-                                          unsigned long long &stamp_prev, int slot0 = 0)
+                                          unsigned long long &stamp_prev, int slot0, WB &wb)
 {
     asm volatile("" : "+v"(lane));
     const int c16 = lane & 15, kg = lane >> 4;
@@ -818,6 +824,7 @@ __device__ __forceinline__ void band_conv(const inv_policy_layer &lp, bf16 *tile
 #pragma unroll
     for (int j = 0; j < NOUT; ++j)
         if (!(POL_BAND_KNOCK & 8)) dst[tid1 + j * THREADS] = zo[j];
+    wb.template items<NOUT>(band * R * WBc * C8, tid1, zo);
     __syncthreads();                                                 // the tile is rebuilt by the next band
     STAMP(slot0 + 3);                                                // z through the tile to global memory
 }
@@ -880,6 +887,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
         bf16 *const z3 = SAVE ? reinterpret_cast<bf16 *>(sv.z[2]) + (size_t)n * G::P * 128 : zW;
         bf16 *const z4 = SAVE ? reinterpret_cast<bf16 *>(sv.z[3]) + (size_t)n * G::P * 128 : zW;
         float s, ss, rstd, shift;
+        NoWriteBackHook nowb;
 #ifdef INV_POLICY_STAMPS
         unsigned long long stamp_prev = stamp_now();                  // phase shares: tools/banded_stamps.py
 #else
@@ -892,7 +900,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
             band_load_obs<G, R, BITS>(tile, obw, planes, band);
             __syncthreads();
             STAMP(0);
-            band_conv<G, R, 32, 32, 1, G::NT / 2, false>(prm.layer[0], tile, z1, band, lane_i, wave & 1, (wave >> 1) * (G::NT / 2), s, ss, stamp_prev, 0);
+            band_conv<G, R, 32, 32, 1, G::NT / 2, false>(prm.layer[0], tile, z1, band, lane_i, wave & 1, (wave >> 1) * (G::NT / 2), s, ss, stamp_prev, 0, nowb);
         }
         band_stats(s, ss, (float)(32 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 0] = rstd; sv.stats[(size_t)n * 8 + 1] = shift; }
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
             band_load_norm<G, R, 32>(tile, z1, prm.layer[0].ln, rstd, shift, band);
             __syncthreads();
             STAMP(4);
-            band_conv<G, R, 32, 64, 1, G::NT, false>(prm.layer[1], tile, z2, band, lane_i, wave, 0, s, ss, stamp_prev, 4);
+            band_conv<G, R, 32, 64, 1, G::NT, false>(prm.layer[1], tile, z2, band, lane_i, wave, 0, s, ss, stamp_prev, 4, nowb);
         }
         band_stats(s, ss, (float)(64 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 2] = rstd; sv.stats[(size_t)n * 8 + 3] = shift; }
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
             band_load_norm<G, R, 64>(tile, z2, prm.layer[1].ln, rstd, shift, band);
             __syncthreads();
             STAMP(8);
-            band_conv<G, R, 64, 128, 2, G::NT, false>(prm.layer[2], tile, z3, band, lane_i, wave * 2, 0, s, ss, stamp_prev, 8);
+            band_conv<G, R, 64, 128, 2, G::NT, false>(prm.layer[2], tile, z3, band, lane_i, wave * 2, 0, s, ss, stamp_prev, 8, nowb);
         }
         band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 4] = rstd; sv.stats[(size_t)n * 8 + 5] = shift; }
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_banded(inv_policy_p
             band_load_norm<G, R, 128>(tile, z3, prm.layer[2].ln, rstd, shift, band);
             __syncthreads();
             STAMP(12);
-            band_conv<G, R, 128, 128, 2, G::NT, true>(prm.layer[3], tile, z4, band, lane_i, wave * 2, 0, s, ss, stamp_prev, 12);
+            band_conv<G, R, 128, 128, 2, G::NT, true>(prm.layer[3], tile, z4, band, lane_i, wave * 2, 0, s, ss, stamp_prev, 12, nowb);
         }
         band_stats(s, ss, (float)(128 * G::P), red, rstd, shift);
         if (SAVE && tid == 0) { sv.stats[(size_t)n * 8 + 6] = rstd; sv.stats[(size_t)n * 8 + 7] = shift; }
@@ -1875,11 +1883,50 @@ __device__ __forceinline__ void band_load_raw(bf16 *tile, const bf16 *__restrict
 
 // da_below[n] = convT(dz[n]) (+ dz[n]: RESIDUAL, the skip connection around conv4).  lp.w: the transposed packing of the layer's
 // weights (inv_policy_pack_conv(transposed = 1)), lp.bias: zeros.
-template <int HB, int WB, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL, bool SPLIT>
-__global__ __launch_bounds__(THREADS, 2) void k_band_conv_t(inv_policy_layer lp, const bf16 *__restrict__ dz, bf16 *__restrict__ da_out, int N)
+// SUMS (round 5): the write-back pass also accumulates what k_band_ln_sums would read da_below back for -- the sample's sums of
+// dx^ = da [x^ w + b > 0] w and of dx^ x^ of the layer BELOW, from the bf16 chunks as they are written and the same expressions, so the
+// mask is the forward's; only the order of the f32 additions differs.  One tensor read (da_below, 4.3 GB at 128 channels) and one
+// launch less per layer.
+template <int C>
+struct LnSumsHook {
+    const bf16x8 *z8;                 // the sample's z of the layer below
+    const void *ln;                   // its packed LayerNorm parameters
+    float rstd, shift, s1, s2;
+    template <int NOUT> __device__ __forceinline__ void items(int first, int tid, const bf16x8 (&da)[NOUT])
+    {
+        bf16x8 zz[NOUT];
+        f16x8 l0[NOUT], l1[NOUT];
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) {
+            const int q = first + tid + j * THREADS;
+            zz[j] = z8[q];
+            const _Float16 *lq = reinterpret_cast<const _Float16 *>(ln) + (size_t)q * 16;
+            l0[j] = *reinterpret_cast<const f16x8 *>(lq);
+            l1[j] = *reinterpret_cast<const f16x8 *>(lq + 8);
+        }
+        POL_PIN();
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = (float)(e < 4 ? l0[j][e] : l1[j][e - 4]), bb = (float)(e < 4 ? l0[j][4 + e] : l1[j][e]);
+                const float xh = fmaf((float)zz[j][e], rstd, shift);
+                const float pre = fmaf(xh, g, bb);                        // ln_relu8's expression: the forward's mask
+                const float dxh = pre > 0.0f ? (float)da[j][e] * g : 0.0f;
+                s1 += dxh;
+                s2 = fmaf(dxh, xh, s2);
+            }
+    }
+};
+
+struct BandSumsArgs { const bf16 *z; const float *stats; const void *ln; float *sums; int layer_below; };
+
+template <int HB, int WB, int R, int CIN, int COUT, int MW, int NW, bool RESIDUAL, bool SPLIT, bool SUMS>
+__global__ __launch_bounds__(THREADS, 2) void k_band_conv_t(inv_policy_layer lp, const bf16 *__restrict__ dz, bf16 *__restrict__ da_out, int N, BandSumsArgs sa)
 {
     using G = BandGeo<HB, WB, R>;
     __shared__ __attribute__((aligned(16))) bf16 tile[G::NPOSB * CSF];
+    __shared__ float red[2 * WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)__builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6));
     for (int i = tid; i < G::NPOSB * CSF / 8; i += THREADS) {
@@ -1897,12 +1944,33 @@ __global__ __launch_bounds__(THREADS, 2) void k_band_conv_t(inv_policy_layer lp,
         const bf16 *src = dz + (size_t)n * G::P * CIN;
         bf16 *dst = da_out + (size_t)n * G::P * COUT;
         float s = 0.0f, ss = 0.0f;                                          // band_conv's statistics: unused here
+        typename std::conditional<SUMS, LnSumsHook<COUT>, NoWriteBackHook>::type hook;
+        if constexpr (SUMS) {
+            hook.z8 = reinterpret_cast<const bf16x8 *>(sa.z + (size_t)n * G::P * COUT);
+            hook.ln = sa.ln;
+            hook.rstd = sa.stats[(size_t)n * 8 + 2 * sa.layer_below];
+            hook.shift = sa.stats[(size_t)n * 8 + 2 * sa.layer_below + 1];
+            hook.s1 = hook.s2 = 0.0f;
+        }
 #pragma unroll 1
         for (int band = 0; band < G::NB; ++band) {
             band_load_raw<G, R, CIN>(tile, src, band);
             __syncthreads();
             unsigned long long stamp_prev = 0;
-            band_conv<G, R, CIN, COUT, MW, NW, RESIDUAL>(lp, tile, dst, band, lane_i, m0, n0, s, ss, stamp_prev, 24);
+            band_conv<G, R, CIN, COUT, MW, NW, RESIDUAL>(lp, tile, dst, band, lane_i, m0, n0, s, ss, stamp_prev, 24, hook);
+        }
+        if constexpr (SUMS) {
+            const float s1 = wave_sum(hook.s1), s2 = wave_sum(hook.s2);
+            if (lane == 0) { red[wave] = s1; red[WAVES + wave] = s2; }
+            __syncthreads();
+            if (tid == 0) {
+                float S1 = 0.0f, S2 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) { S1 += red[w]; S2 += red[WAVES + w]; }
+                sa.sums[(size_t)n * 2] = S1;
+                sa.sums[(size_t)n * 2 + 1] = S2;
+            }
+            __syncthreads();                                                // red[] is rewritten by the next sample
         }
     }
 }
@@ -2193,13 +2261,10 @@ extern "C" int inv_policy_band_ln_bwd2(int32_t layer, int32_t height, int32_t wi
     return launch_status("inv_policy_band_ln_bwd2");
 }
 
-extern "C" int inv_policy_band_conv_t(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,
-                                      const void *dz_bf16, void *da_below_bf16, int32_t N, void *stream)
+template <bool SUMS>
+static int launch_band_conv_t(int32_t layer, const void *wt_packed, const float *zero_bias, const void *dz_bf16, void *da_below_bf16, int32_t N, void *stream,
+                              const pol::BandSumsArgs &sa)
 {
-    if (!wt_packed || !zero_bias || !dz_bf16 || !da_below_bf16 || N < 0 || layer < 1 || layer > 3)
-        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_conv_t: NULL tensor, N < 0 or layer outside 1..3 (layer 0 has no data gradient)");
-    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_conv_t: built for the 32 x 32 board");
-    if (N == 0) return INV_OK;
     const int grid = trunk_grid(N);
     inv_policy_layer lp;
     lp.w = wt_packed; lp.bias = zero_bias; lp.ln = nullptr;
@@ -2208,12 +2273,37 @@ extern "C" int inv_policy_band_conv_t(int32_t layer, int32_t height, int32_t wid
     const bf16 *src = reinterpret_cast<const bf16 *>(dz_bf16);
     bf16 *dst = reinterpret_cast<bf16 *>(da_below_bf16);
     if (layer == 3)        // dz4 [128] -> da3 [128], + dz4 (residual)
-        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 128, 128, 2, G::NT, true, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N);
+        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 128, 128, 2, G::NT, true, false, SUMS>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N, sa);
     else if (layer == 2)   // dz3 [128] -> da2 [64]
-        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 128, 64, 1, G::NT, false, false>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N);
+        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 128, 64, 1, G::NT, false, false, SUMS>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N, sa);
     else                   // dz2 [64] -> da1 [32]
-        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 64, 32, 1, G::NT / 2, false, true>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N);
-    return launch_status("inv_policy_band_conv_t");
+        hipLaunchKernelGGL((pol::k_band_conv_t<32, 32, 4, 64, 32, 1, G::NT / 2, false, true, SUMS>), dim3(grid), dim3(pol::THREADS), 0, (hipStream_t)stream, lp, src, dst, (int)N, sa);
+    return launch_status(SUMS ? "inv_policy_band_conv_t_sums" : "inv_policy_band_conv_t");
+}
+
+extern "C" int inv_policy_band_conv_t(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,
+                                      const void *dz_bf16, void *da_below_bf16, int32_t N, void *stream)
+{
+    if (!wt_packed || !zero_bias || !dz_bf16 || !da_below_bf16 || N < 0 || layer < 1 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_conv_t: NULL tensor, N < 0 or layer outside 1..3 (layer 0 has no data gradient)");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_conv_t: built for the 32 x 32 board");
+    if (N == 0) return INV_OK;
+    pol::BandSumsArgs none;
+    memset(&none, 0, sizeof none);
+    return launch_band_conv_t<false>(layer, wt_packed, zero_bias, dz_bf16, da_below_bf16, N, stream, none);
+}
+
+extern "C" int inv_policy_band_conv_t_sums(int32_t layer, int32_t height, int32_t width, const void *wt_packed, const float *zero_bias,
+                                           const void *dz_bf16, void *da_below_bf16, const void *z_below_bf16, const float *stats,
+                                           const void *ln_below_packed, float *sums_below, int32_t N, void *stream)
+{
+    if (!wt_packed || !zero_bias || !dz_bf16 || !da_below_bf16 || !z_below_bf16 || !stats || !ln_below_packed || !sums_below || N < 0 || layer < 1 || layer > 3)
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_band_conv_t_sums: NULL tensor, N < 0 or layer outside 1..3 (layer 0 has no data gradient)");
+    if (!band_dims_ok(height, width)) return inv_fail(INV_ERR_BAD_DIMS, "inv_policy_band_conv_t_sums: built for the 32 x 32 board");
+    if (N == 0) return INV_OK;
+    pol::BandSumsArgs sa;
+    sa.z = reinterpret_cast<const pol::bf16 *>(z_below_bf16); sa.stats = stats; sa.ln = ln_below_packed; sa.sums = sums_below; sa.layer_below = layer - 1;
+    return launch_band_conv_t<true>(layer, wt_packed, zero_bias, dz_bf16, da_below_bf16, N, stream, sa);
 }
 
 extern "C" int inv_policy_band_act(int32_t layer, int32_t height, int32_t width, const void *z_bf16, const float *stats, const void *ln_packed,

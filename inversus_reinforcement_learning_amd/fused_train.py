@@ -292,17 +292,20 @@ class _TrunkTrainBandedFn(torch.autograd.Function):
             grads[4 * l] = dw[:, :, :cin].reshape(c, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
             grads[4 * l + 1] = db
 
-        # l = 3 .. 0:  ln_sums(l) [da_l, z_l -> the sample's two sums]  ->  ln_bwd2(l) [da_l, z_l -> dz_l, a_l, LayerNorm parameter sums]
-        #              ->  wgrad(l + 1) [a_l, dz_{l+1}]  ->  conv_t(l) [dz_l -> da_{l-1}];  finally wgrad(0) [x0, dz_0]
+        # l = 3 .. 0:  ln_sums(l) [da_l, z_l -> the sample's two sums; l < 3: left behind by conv_t(l + 1)'s write-back, ABI 7]
+        #              ->  ln_bwd2(l) [da_l, z_l -> dz_l, a_l, LayerNorm parameter sums]
+        #              ->  wgrad(l + 1) [a_l, dz_{l+1}]  ->  conv_t(l) [dz_l -> da_{l-1}, sums of layer l - 1];  finally wgrad(0) [x0, dz_0]
+        fused_sums = os.environ.get("INVERSUS_BAND_FUSED_SUMS", "1") != "0"
         with torch.cuda.device(dev):
-            dz_above = None
+            dz_above, sums = None, None
             for l in (3, 2, 1, 0):
                 c = _COUT[l]
                 dz = torch.empty_like(z[l])
                 act = torch.empty_like(z[l]) if l < 3 else None
                 # two tensor passes over (da, z): the sample's two sums, then dz + activation + LayerNorm parameter partial sums in one
-                sums = torch.empty((n, 2), dtype=torch.float32, device=dev)
-                L.raise_for(lib.inv_policy_band_ln_sums(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(sums), n, st()), lib)
+                if sums is None:
+                    sums = torch.empty((n, 2), dtype=torch.float32, device=dev)
+                    L.raise_for(lib.inv_policy_band_ln_sums(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(sums), n, st()), lib)
                 slices = max(1, min(n, _RED_SLICES))
                 part = torch.empty((slices, 2, pix, c), dtype=torch.float32, device=dev)
                 L.raise_for(lib.inv_policy_band_ln_bwd2(l, hb, wb, _ptr(da), _ptr(z[l]), _ptr(stats), _ptr(lns[l]), _ptr(sums), _ptr(dz),
@@ -316,7 +319,13 @@ class _TrunkTrainBandedFn(torch.autograd.Function):
                 if l >= 1:
                     wt = pack_conv(ws[l], _COUT[l], transposed=True)
                     da = torch.empty((n, pix, _COUT[l - 1]), dtype=torch.bfloat16, device=dev)
-                    L.raise_for(lib.inv_policy_band_conv_t(l, hb, wb, _ptr(wt), _ptr(zero_bias), _ptr(dz), _ptr(da), n, st()), lib)
+                    if fused_sums:
+                        sums = torch.empty((n, 2), dtype=torch.float32, device=dev)
+                        L.raise_for(lib.inv_policy_band_conv_t_sums(l, hb, wb, _ptr(wt), _ptr(zero_bias), _ptr(dz), _ptr(da), _ptr(z[l - 1]), _ptr(stats),
+                                                                    _ptr(lns[l - 1]), _ptr(sums), n, st()), lib)
+                    else:
+                        sums = None
+                        L.raise_for(lib.inv_policy_band_conv_t(l, hb, wb, _ptr(wt), _ptr(zero_bias), _ptr(dz), _ptr(da), n, st()), lib)
                 dz_above = dz
             x0 = torch.empty((n, pix, 16), dtype=torch.bfloat16, device=dev)
             L.raise_for(lib.inv_policy_obs_to_x0_any(_ptr(obs), 1 if ctx.bits else 0, pix, _ptr(x0), n, st()), lib)

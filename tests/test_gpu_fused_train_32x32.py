@@ -98,6 +98,45 @@ def test_band_conv_t_matches_the_data_gradient_of_conv2d(layer):
     assert rel(da, want) < 6e-3, rel(da, want)                              # bf16 output rounding
 
 
+@pytest.mark.parametrize("layer,n", [(1, 3), (2, 5), (3, 700)])
+def test_band_conv_t_sums_leaves_the_data_gradient_and_the_layer_belows_two_sums(layer, n):
+    """ABI 7: conv_t(l) with the LayerNorm-backward sums of layer l - 1 taken from its write-back pass.  The data gradient is the
+    plain entry point's bit for bit; the sums are inv_policy_band_ln_sums' on that tensor up to the order of the f32 additions.
+    n = 700 > the grid: a workgroup handles several samples, so its accumulators and the LDS reduction are reused."""
+    import torch
+    from inversus_reinforcement_learning_amd import _lib as L, fused_train as FT
+    from inversus_reinforcement_learning_amd.fused_policy import pack_conv, pack_ln
+    lib = L.load()
+    torch.manual_seed(20 + layer)
+    cin, cout = FT._CIN[layer], FT._COUT[layer]
+    w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.1
+    dz = (torch.randn(n, P, cout, device="cuda") * 0.5).to(torch.bfloat16)
+    wt = pack_conv(w, cout, transposed=True)
+    zero = torch.zeros(128, device="cuda")
+    zb = (torch.randn(n, P, cin, device="cuda") * 1.5 + 0.3).to(torch.bfloat16)          # z of the layer below
+    gw = (1.0 + 0.2 * torch.randn(cin, H, W, device="cuda")).half().float()
+    gb = (0.2 * torch.randn(cin, H, W, device="cuda")).half().float()
+    ln = pack_ln(gw, gb, cin)
+    zf = zb.float()
+    mean = zf.mean(dim=(1, 2))
+    rstd = 1.0 / torch.sqrt(zf.var(dim=(1, 2), unbiased=False) + 1e-5)
+    stats = torch.zeros(n, 4, 2, device="cuda")
+    stats[:, layer - 1, 0], stats[:, layer - 1, 1] = rstd, -mean * rstd
+    da = torch.empty(n, P, cin, dtype=torch.bfloat16, device="cuda")
+    L.raise_for(lib.inv_policy_band_conv_t(layer, H, W, _p(wt), _p(zero), _p(dz), _p(da), n, _st()), lib)
+    want = torch.full((n, 2), float("nan"), device="cuda")
+    L.raise_for(lib.inv_policy_band_ln_sums(layer - 1, H, W, _p(da), _p(zb), _p(stats), _p(ln), _p(want), n, _st()), lib)
+    da2 = torch.full_like(da, 7.0)
+    got = torch.full((n, 2), float("nan"), device="cuda")
+    L.raise_for(lib.inv_policy_band_conv_t_sums(layer, H, W, _p(wt), _p(zero), _p(dz), _p(da2), _p(zb), _p(stats), _p(ln), _p(got), n, _st()), lib)
+    assert torch.equal(da2, da)
+    # a sum of ~1e5 terms of mixed sign in f32: compare against the size of the terms, not of the (cancelling) total
+    scale = (da.float().abs().sum(dim=(1, 2)) * float(gw.abs().max()) * 5.0).clamp_min(1.0)       # |x^| < 5 on these inputs
+    assert float(((got - want).abs().max(dim=1).values / scale).max()) < 1e-5, ((got - want).abs().max(), scale.min())
+    with pytest.raises(ValueError, match="NULL tensor"):
+        L.raise_for(lib.inv_policy_band_conv_t_sums(layer, H, W, _p(wt), _p(zero), _p(dz), _p(da2), None, _p(stats), _p(ln), _p(got), n, _st()), lib)
+
+
 @pytest.mark.parametrize("layer", [0, 3])
 def test_band_ln_bwd_act_and_param_grads_match_autograd(layer):
     import torch
