@@ -52,6 +52,29 @@ def test_banded_trunk_matches_the_f32_module(n):
     assert float((logits - lw).abs().max()) < 0.05 and float((value - vw).abs().max()) < 0.05
 
 
+def test_banded_trunk_never_reads_scratch_it_has_not_written():
+    """Round 5: the four layers' z share ONE scratch buffer per workgroup and a layer overwrites rows of its own input that it has
+    already fetched.  Whatever the buffer held before the launch must not matter: NaN-filled and zero-filled scratch give the same
+    features, with more samples than workgroups (a workgroup reuses its buffer for several samples) and with one."""
+    import torch
+    import ctypes as C
+    from inversus_reinforcement_learning_amd import _lib as L
+    from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
+    fused = FusedPolicy(make_policy(torch, seed=3))
+    lib = L.load()
+    want_bytes = int(lib.inv_policy_trunk_banded_scratch_bytes(32, 32))
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert want_bytes == 2 * cus * 1024 * 128 * 2                                # 2 workgroups per CU, one [P][128] bf16 buffer each
+    for n in (1, 700):
+        _, bits, _ = env_observations(torch, n, steps=6)
+        base = fused.features(bits).clone()
+        for fill in (0xFF, 0x00):                                              # 0xFFFF is a bf16 NaN
+            for buf in FusedPolicy._banded_scratch.values():
+                buf.fill_(fill)
+            assert torch.equal(fused.features(bits), base), (n, fill)
+        assert bool(torch.isfinite(base.float()).all())
+
+
 def test_banded_trunk_rejects_other_boards():
     import torch
     from inversus_reinforcement_learning_amd.fused_policy import FusedPolicy
