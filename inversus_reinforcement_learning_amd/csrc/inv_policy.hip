@@ -71,6 +71,12 @@ constexpr float LN_EPS = 1e-5f;
 // Timing probes of the banded forward (tools/band_knock_ab.sh; the results are WRONG on purpose): 1 no MFMAs, 2 no weight-fragment
 // reloads in the k loop, 4 no global loads in the band input pass, 8 no z write-back stores, 16 no B-fragment LDS reads in the k
 // loop, 32 no feature pass
+#ifndef POL_TRUNK_KNOCK
+#define POL_TRUNK_KNOCK 0                  // the 15 x 10 GEMM core's timing probes (tools/trunk_knock_ab.sh): 1 no MFMAs (operands still loaded), 2 no weight-fragment reloads, 16 no B-fragment LDS reads inside the loop, 32 no LayerNorm-parameter loads in the inference epilogue
+#endif
+#if POL_TRUNK_KNOCK && !defined(INV_TOOLS_BUILD)
+#error "POL_TRUNK_KNOCK builds compute wrong features on purpose (timing probes): tools/build_variant.py only (it defines INV_TOOLS_BUILD)"
+#endif
 #ifndef POL_BAND_KNOCK
 #define POL_BAND_KNOCK 0
 #elif !defined(INV_TOOLS_BUILD)
@@ -172,27 +178,33 @@ __device__ __forceinline__ void conv_gemm_rows(const void *w, const bf16 *tile, 
             a[slot][dy_][mi_] = wp[((size_t)mi_ * KS + (dy_ * 3 + (g) % 3) * KPT + (g) / 3) * 64]
 #define POL_ROWS_B(t) (*reinterpret_cast<const bf16x8 *>(rp + ((JQ0 + (t) % NR) * PW + ((t) / NR) % 3) * CSF + (((t) / NR) / 3) * 32))
 #pragma unroll
-    for (int g = 0; g < PG; ++g) { POL_ROWS_A(g, g); }
+    for (int g = 0; g < ((POL_TRUNK_KNOCK & 2) ? 1 : PG); ++g) { POL_ROWS_A(g, g); }
 #pragma unroll
     for (int t = 0; t < BD - 1; ++t) b[t] = POL_ROWS_B(t < NS ? t : NS - 1);
     // two nested fully unrolled loops (one flat loop of NS steps exceeds the unroller's size budget for pragma loops and is left
     // rolled, with the fragment arrays in scratch): every index below is a constant after unrolling
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        if (NG > 3 && g + 1 < NG) { POL_ROWS_A(g + 1, (g + 1) & 1); }
+        if (!(POL_TRUNK_KNOCK & 2) && NG > 3 && g + 1 < NG) { POL_ROWS_A(g + 1, (g + 1) & 1); }
         if (g == NG - 1) { early(); POL_PIN(); }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int t = g * NR + r, jq = JQ0 + r;
-            if (t + BD - 1 < NS) b[(t + BD - 1) % BD] = POL_ROWS_B(t + BD - 1);
+            if (!(POL_TRUNK_KNOCK & 16) && t + BD - 1 < NS) b[(t + BD - 1) % BD] = POL_ROWS_B(t + BD - 1);
             POL_PIN();
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int i = jq - dy;                               // output row (relative to n0) this input row serves through tap row dy
                 if (i >= 0 && i < NW) {
 #pragma unroll
-                    for (int mi = 0; mi < MW; ++mi)
-                        acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g % NSLOT][dy][mi], b[t % BD], acc[mi][i], 0, 0, 0);
+                    for (int mi = 0; mi < MW; ++mi) {
+                        if (POL_TRUNK_KNOCK & 1) {
+                            typedef unsigned int knock_u4 __attribute__((ext_vector_type(4)));
+                            asm volatile("" :: "v"(__builtin_bit_cast(knock_u4, a[(POL_TRUNK_KNOCK & 2) ? 0 : g % NSLOT][dy][mi])), "v"(__builtin_bit_cast(knock_u4, b[t % BD])));
+                        } else {
+                            acc[mi][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(POL_TRUNK_KNOCK & 2) ? 0 : g % NSLOT][dy][mi], b[t % BD], acc[mi][i], 0, 0, 0);
+                        }
+                    }
                 }
             }
             POL_PIN();
@@ -272,6 +284,11 @@ __device__ __forceinline__ void conv_ln_relu(const inv_policy_layer &lp, bf16 *t
             for (int mi = 0; mi < MW; ++mi)
 #pragma unroll
                 for (int i = 0; i < NW; ++i) {
+                    if (POL_TRUNK_KNOCK & 32) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ln[mi][i][e] = (_Float16)(e < 4 ? 1.0f : 0.25f);
+                        continue;
+                    }
                     ln[mi][i] = *reinterpret_cast<const f16x8 *>(reinterpret_cast<const _Float16 *>(lp.ln) +
                                                                  ((size_t)min(pix[i], P - 1) * COUT + (m0 + mi) * 16 + 4 * kg) * 2);
                 }
