@@ -38,7 +38,10 @@ if ROOT not in sys.path:
 
 NUM_ENVS = 16384            # per GPU (BASELINE.json metric: "env-steps/sec at 16384 envs")
 W, H, K = 15, 10, 16
-EV_GROUP = 10
+# HIP-event groups inside a timed region: 0 = ONE pair around the region's K launches (the default: an event record is a queue marker
+# that costs the stream ~1 us, and with a pair every 10 launches -- rounds 1-4 -- the markers were 0.3-0.5 us per step of `value`'s wall
+# clock); N > 0 = a pair around every N launches (diagnostics: per-group times).
+EV_GROUP = int(os.environ.get("INVERSUS_BENCH_EV_GROUP", "0"))
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 
 
@@ -777,6 +780,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:                 # no launcher: be the launcher (before any GPU call)
         raise SystemExit(spawn_ranks(args.gpus))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC (RCCL across processes on this driver); before HIP starts
     import torch
     import torch.distributed as dist
     from inversus_reinforcement_learning_amd.device_env import DeviceEnvBatch
@@ -857,10 +861,10 @@ def main():
     else:
         gpus, ranks_seen = [me], 1
 
-    # HIP events on the launch stream around groups of EV_GROUP consecutive k_step launches (an event
-    # pair per launch costs ~2 us of queue markers per step); kernel_ms = group time / launches, so it
-    # includes the ~1.5 us dependent-launch boundary between steps of one env batch.
-    groups = [(k, min(k + EV_GROUP, args.steps)) for k in range(0, args.steps, EV_GROUP)]
+    # HIP events on the launch stream around the region's k_step launches (one pair per region, or per EV_GROUP launches);
+    # kernel_ms = event time / launches, so it includes the ~1.5 us dependent-launch boundary between steps of one env batch.
+    evg = EV_GROUP if EV_GROUP > 0 else max(1, args.steps)
+    groups = [(k, min(k + evg, args.steps)) for k in range(0, args.steps, evg)]
 
     def timed_loop(slots_n, repeats):
         """`repeats` regions of exactly args.steps vector steps into `slots_n` output buffers (slot = step % slots_n; no allocator in
@@ -939,7 +943,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(args.difficulty, "_streaming"),
                          "regime": "streaming: every launch writes its 118 MB of observations to a buffer of its own (32 slots, 3.8 GB)",
                          "kernel": "k_step4 (four envs per wavefront; csrc/inv_step4.h)" if b.step_kernel != "wave" else "k_step",
-                         "kernel_ms": kern_ms_roof, "kernel_ms_per_rank": [round(x, 6) for x in kern_ms_ranks],
+                         "kernel_ms": kern_ms_roof, "kernel_ms_events": ("one HIP-event pair around each timed region" if EV_GROUP <= 0 else f"a HIP-event pair per {EV_GROUP} launches"),
+                         "kernel_ms_per_rank": [round(x, 6) for x in kern_ms_ranks],
                          "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step()},
         }
         if cregions is not None:
