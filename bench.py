@@ -885,8 +885,12 @@ def main():
                 for k in range(lo, hi):
                     stp[k % slots_n](base + (args.warmup + k) * n)
                 e1.record()
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0                # THIS rank's K steps, complete on its GPU
+            # the closing barrier + synchronize follow at once, but the barrier's OWN latency (a collective of tens of us -- ms under
+            # gloo -- against a 0.5-ms region at the driver's 20 steps) is not part of the K steps: the region's time is the MAX over
+            # ranks of the per-rank times (ranks leave the opening barrier together), i.e. when the slowest shard finished
             fence()
-            dt_ = time.perf_counter() - t0
             regs.append((over_ranks(dt_, dist.ReduceOp.MAX), sum(s_.elapsed_time(e_) for s_, e_ in ev) / args.steps))
         b.check()
         del so, slots, stp
@@ -934,7 +938,7 @@ def main():
                        "envs_per_gpu": n, "sharding": f"env-shards x{world}, no data-path collective",
                        "backend": (args.backend if use_dist else "none"), "gpu": gpus[0], "gpus": gpus, "ranks_seen": ranks_seen,
                        "distinct_gpus": len({g.get("uuid") or f"no-uuid-{g.get('rank')}" for g in gpus})},
-            "repeats": len(regions), "protocol": "median of the repeats' wall time (each = exactly `steps` vector steps, barrier + synchronize on both sides)",
+            "repeats": len(regions), "protocol": "median of the repeats' wall time (each = exactly `steps` vector steps between barrier + synchronize on both sides; a rank's clock stops at its own synchronize, the region is the MAX over ranks)",
             "ms_per_step_repeats": [round(r[0] / args.steps * 1e3, 6) for r in regions],
             # `value`, `achieved`, `frac`, `kernel_ms` all describe ONE loop: the launches that write 32 distinct buffers, i.e. HBM traffic.
             # The *_cache_resident fields are the same launches re-writing one 118 MB buffer (the Infinity Cache absorbs it): rounds 1-3
