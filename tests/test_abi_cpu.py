@@ -99,3 +99,28 @@ def test_graft_entry_build_runs():
     library and checks the ABI version against the header."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_the_c_example_of_integration_md_compiles_against_the_header(tmp_path):
+    """INTEGRATION.md section C (the C / C++ caller) is compiled as written -- as C99 by gcc and as C++ by g++ -- against
+    include/inversus_hip.h: the documented call sequence cannot drift from the declared signatures."""
+    import shutil
+    import subprocess
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## C. From C / C++"):]
+    block = re.findall(r"```c\n(.*?)```", sec, flags=re.S)
+    assert block, "INTEGRATION.md section C holds a C block"
+    lines = block[0].strip().splitlines()
+    assert lines[0].startswith("#include")
+    body = "\n    ".join(lines[1:])
+    src = ("#include <stdio.h>\n#include <stdint.h>\n" + lines[0] + "\n"
+           "int integration_example(const int64_t *seeds_host, float *d_obs, float *d_extra, float *d_reward, uint8_t *d_done,\n"
+           "                        const uint8_t *d_a1, void *stream, int T)\n{\n    " + body + "\n    return inv_destroy(h);\n}\n")
+    for cc, ext, std in (("gcc", "c", "-std=c99"), ("g++", "cpp", "-std=c++20")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not found")
+        f = tmp_path / f"example.{ext}"
+        f.write_text(src)
+        r = subprocess.run([cc, std, "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(f)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
