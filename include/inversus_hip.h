@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define INV_ABI_VERSION 7
+#define INV_ABI_VERSION 8
 
 typedef enum {
     INV_OK = 0,
@@ -169,6 +169,14 @@ int  inv_step(inv_handle *h, const uint8_t *a1, const uint8_t *a2, uint32_t flag
  * and their output slots are not written (SingleInversusRLEnv.step on runner.envs[i]). */
 int  inv_step_masked(inv_handle *h, const uint8_t *mask, const uint8_t *a1, const uint8_t *a2, uint32_t flags,
                      const inv_step_out *out, void *stream);
+
+/* dummy_opponent_policy(env, difficulty) (env_wrappers.py:69-170) for every env of the handle, WITHOUT stepping it (ABI 8):
+ * actions[i] (device, uint8_t[N]) = the P2 action id (0..8: the dummy never charges) the device dummy takes for env i's current
+ * state -- what inv_step with a2 == NULL would apply next when the handle's difficulty is `difficulty` (INV_EASY / INV_HARD; like
+ * the reference's argument it need not be the handle's own).  The reference draws from the global `random`; the device dummy's
+ * draws are a counter hash keyed by (opp_seed, global env index, steps taken against the dummy so far), which this call reads
+ * and does not advance: calling it twice without a step in between returns the same actions. */
+int  inv_dummy_actions(inv_handle *h, int32_t difficulty, uint8_t *actions, void *stream);
 
 /* build_observation(env, player) (env_wrappers.py:173-245); player 0 = P1, 1 = P2. */
 int  inv_render_obs(inv_handle *h, int32_t player, float *obs, float *extra, void *stream);

@@ -8,12 +8,12 @@ raises if the HIP library or the GPU is missing (there is no CPU fallback).
 from .vocab import Action, ActionType, Bullet, Direction, PlayerId, PlayerState, TileColor  # noqa: F401
 
 __all__ = ["Action", "ActionType", "Bullet", "Direction", "PlayerId", "PlayerState", "TileColor",
-           "MultiEnvRunner", "SingleInversusRLEnv", "build_observation", "discrete_to_action",
+           "MultiEnvRunner", "SingleInversusRLEnv", "build_observation", "discrete_to_action", "dummy_opponent_policy",
            "DeviceEnvBatch", "gae"]
 
 
 def __getattr__(name):          # lazy: keep `import inversus_reinforcement_learning_amd` torch-free and fast
-    if name in ("MultiEnvRunner", "SingleInversusRLEnv", "build_observation", "discrete_to_action"):
+    if name in ("MultiEnvRunner", "SingleInversusRLEnv", "build_observation", "discrete_to_action", "dummy_opponent_policy"):
         from . import env_wrappers
         return getattr(env_wrappers, name)
     if name in ("DeviceEnvBatch", "gae"):

@@ -112,6 +112,7 @@ SIGNATURES = {
     "inv_reset": (C.c_int, [_V, _V, _V]),
     "inv_step": (C.c_int, [_V, _V, _V, C.c_uint32, P(InvStepOut), _V]),
     "inv_step_masked": (C.c_int, [_V, _V, _V, _V, C.c_uint32, P(InvStepOut), _V]),
+    "inv_dummy_actions": (C.c_int, [_V, C.c_int32, _V, _V]),
     "inv_render_obs": (C.c_int, [_V, C.c_int32, _V, _V, _V]),
     "inv_render_obs_bits": (C.c_int, [_V, C.c_int32, _V, _V, _V]),
     "inv_unpack_obs": (C.c_int, [_V, C.c_int64, C.c_int32, _V, _V]),

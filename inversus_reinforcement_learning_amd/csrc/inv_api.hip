@@ -409,6 +409,23 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void k_render(Dims dd, Stat
                obs + (size_t)env * (as_bits ? (size_t)d.OW : (size_t)12 * d.WH), extra ? extra + (size_t)env * 4 : nullptr, as_bits != 0, obs_wt != 0);
 }
 
+// dummy_opponent_policy (env_wrappers.py:69-170) as a function of its own: the P2 action id the device dummy takes at every env's
+// NEXT step, from the env's current state and counter; nothing is written back (the counter advances only when a step consumes it).
+template <class D>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void k_dummy_actions(Dims dd, State s, int hard, uint32_t opp_seed, uint32_t env_offset, uint8_t *out)
+{
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (kWave - 1), wv = rfl((int)(threadIdx.x >> 6));
+    const int env = blockIdx.x * kWavesPerBlock + wv;
+    if (env >= dd.N) return;
+    const D d(dd);
+    const WaveLds<D> L(d, lds, wv);
+    Env e;
+    load_env(d, s, env, lane, L.g, e);
+    const int act = rfl(dummy_action(d, L.g, lane, e, hard, opp_seed, env_offset + (uint32_t)env, e.opp_ctr));
+    if (lane == 0) out[env] = (uint8_t)act;
+}
+
 // Packed observation bitstring -> f32 planes: float4 q of env i = nibble (q & 7) of word q >> 3 (the same
 // expansion render_obs applies in LDS), for the consumers that want f32 (the PPO update's minibatches).
 __global__ __launch_bounds__(256) void k_unpack_obs(const uint32_t *__restrict__ bits, long long total, int f4_per_env, int words_per_env,
@@ -841,6 +858,17 @@ static int launch_render(inv_handle *h, int32_t player, float *obs, float *extra
     if (player != 0 && player != 1) return fail(INV_ERR_BAD_ARG, "Invalid player ID: %d", player);   // core.py:198
     INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL(k_render<DT>, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes,
                                                (hipStream_t)stream, h->d, h->s, player, obs, extra, as_bits, as_bits ? 0 : obs_write_through(h, false, obs, nullptr)));
+    HIP_TRY(hipGetLastError());
+    return INV_OK;
+}
+
+int inv_dummy_actions(inv_handle *h, int32_t difficulty, uint8_t *actions, void *stream)
+{
+    if (!h || !actions) return fail(INV_ERR_BAD_ARG, "inv_dummy_actions: NULL argument");
+    if (difficulty != INV_EASY && difficulty != INV_HARD) return fail(INV_ERR_BAD_ARG, "inv_dummy_actions: difficulty must be INV_EASY or INV_HARD");
+    INV_DISPATCH_DIMS(h->d, hipLaunchKernelGGL(k_dummy_actions<DT>, dim3(env_blocks(h->d.N)), dim3(kWave * kWavesPerBlock), h->lds_bytes,
+                                               (hipStream_t)stream, h->d, h->s, difficulty == INV_HARD ? 1 : 0, h->cfg.opp_seed,
+                                               (uint32_t)h->cfg.env_offset, actions));
     HIP_TRY(hipGetLastError());
     return INV_OK;
 }

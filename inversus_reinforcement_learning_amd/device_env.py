@@ -220,6 +220,19 @@ class DeviceEnvBatch:
             L.raise_for(fn(self.h, int(player), _ptr(out[0]), _ptr(out[1]), _stream()), self.lib)
         return out
 
+    def dummy_actions(self, difficulty=None, out=None):
+        """dummy_opponent_policy (env_wrappers.py:69-170) for every env without stepping it: uint8[N] action ids (0..8) the
+        device dummy takes for the current states -- what the next step(a1, None) applies when the batch's difficulty is
+        `difficulty` ("easy" / "hard"; default: the batch's own).  Its counter RNG is read, not advanced."""
+        d = self.difficulty if difficulty is None else difficulty
+        if d not in ("easy", "hard"):
+            raise ValueError(f"Unknown difficulty: {d}")
+        if out is None:
+            out = self._new((self.num_envs,), torch.uint8)
+        with torch.cuda.device(self.device):
+            L.raise_for(self.lib.inv_dummy_actions(self.h, L.INV_HARD if d == "hard" else L.INV_EASY, _ptr(out), _stream()), self.lib)
+        return out
+
     def uniform_actions(self, seed, t, out=None):
         if out is None:
             out = self._new((self.num_envs,), torch.uint8)

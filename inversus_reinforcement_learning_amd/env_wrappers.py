@@ -5,6 +5,7 @@ HIP kernels: same class / function names, argument order, return shapes and exce
     SingleInversusRLEnv(opponent_type, difficulty, max_episode_steps, seed)        :248-444
     build_observation(env, player_id)                                              :173-245
     discrete_to_action(action_id)                                                  :20-66
+    dummy_opponent_policy(env, difficulty)                                         :69-170
 
 Differences a caller can see (all additive, keyword-only):
   * `output="numpy"` (default) returns fresh host arrays exactly like the reference;
@@ -38,6 +39,20 @@ def discrete_to_action(action_id):
     if a == 0:
         return Action(ActionType.NONE, None)
     return Action(TYPE_BY_CODE[(a + 3) >> 2], DIR_BY_CODE[(a - 1) & 3])
+
+
+def dummy_opponent_policy(env, difficulty="easy"):
+    """The scripted dummy's action for P2 in `env`'s current state (env_wrappers.py:69-170): 'easy' = the sitting duck (moves in
+    0.1 % of the steps, never shoots), anything else = the hunter (20 % shots when aligned, 5 % random moves, otherwise towards P1).
+    `env` is the core object the reference passes (`rl_env.env` / `runner.envs[i].env`; an rl env or a `runner.envs[i]` handle is
+    accepted too).  The decision is the device dummy's (inv_dummy_actions): the same function of the state as the reference's, its
+    draws from the env's counter RNG instead of the global `random` -- so repeated calls without a step in between agree, and the
+    returned action is the one the env's next step against the dummy applies."""
+    core = env.env if isinstance(env, (SingleInversusRLEnv, _EnvHandle)) else env
+    if not isinstance(core, _CoreView):
+        raise TypeError("dummy_opponent_policy expects an env object of this package")
+    a2 = core._batch.dummy_actions("easy" if difficulty == "easy" else "hard")
+    return discrete_to_action(int(a2[core._i].item()))
 
 
 def _entropy_seed():

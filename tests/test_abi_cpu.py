@@ -34,7 +34,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(declared_symbols())
     import re
     with open(os.path.join(ROOT, "include", "inversus_hip.h")) as fh:
-        assert lib.inv_abi_version() == int(re.search(r"#define\s+INV_ABI_VERSION\s+(\d+)", fh.read()).group(1)) == 7
+        assert lib.inv_abi_version() == int(re.search(r"#define\s+INV_ABI_VERSION\s+(\d+)", fh.read()).group(1)) == 8
 
 
 def test_code_object_is_gfx950():
