@@ -244,6 +244,26 @@ class _CoreView:
         st["nbullets"][self._i] = len(lst)
         self._batch.set_state(bullets=st["bullets"], nbullets=st["nbullets"])
 
+    # ---- legacy accessors of player 1's position (core.py:156-181; the reference's tests/test_core_basic.py:15-43 move the
+    # player with them).  As in the reference, ASSIGNING player_y also clears the bullet list (core.py:179-181: the two lines sit
+    # inside that setter).
+    @property
+    def player_x(self):
+        return self.player1.x
+
+    @player_x.setter
+    def player_x(self, value):
+        self.player1.x = value
+
+    @property
+    def player_y(self):
+        return self.player1.y
+
+    @player_y.setter
+    def player_y(self, value):
+        self.player1.y = value
+        self.bullets = []
+
     # ---- reads (core.py:183-247, 477-495)
     def get_player(self, pid):
         if pid == PlayerId.P1:

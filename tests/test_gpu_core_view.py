@@ -130,3 +130,24 @@ def test_reset_through_the_view_continues_the_env_stream():
     o.reset()                                                            # the runner's constructor reset + this one
     env.reset()
     assert (env.player1.x, env.player1.y, env.player2.x, env.player2.y) == tuple(o.players()[:, :2].reshape(-1))
+
+
+def test_legacy_player_position_accessors():
+    """core.py:156-181 (`env.player_x`, `env.player_y`): the reference's tests/test_core_basic.py:9-43 places player 1 with
+    them, moves it onto a walkable tile and is blocked by a tile of its own colour; assigning player_y also clears the bullets."""
+    from inversus_reinforcement_learning_amd.vocab import Bullet, Direction, PlayerId, TileColor
+    runner, env = make(15, 10)
+    env.player_x = 2
+    env.player_y = 2
+    assert (env.player1.x, env.player1.y) == (2, 2) == (env.player_x, env.player_y) == env.get_player_position()
+    env._set_tile(3, 2, TileColor.WHITE)                                # walkable for P1 (BLACK walks on WHITE)
+    assert env.try_move_player(Direction.RIGHT) is True
+    assert (env.player_x, env.player_y) == (3, 2)
+    env._set_tile(4, 2, TileColor.BLACK)                                # its own colour: blocked
+    assert env.try_move_player(Direction.RIGHT) is False
+    assert (env.player_x, env.player_y) == (3, 2)
+    env.bullets = [Bullet(7, 7, Direction.UP, PlayerId.P2)]
+    env.player_x = 5
+    assert len(env.bullets) == 1                                        # player_x leaves them alone ...
+    env.player_y = 6
+    assert env.bullets == [] and (env.player1.x, env.player1.y) == (5, 6)   # ... player_y clears them (core.py:179-181)
