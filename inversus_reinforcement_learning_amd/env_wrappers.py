@@ -389,6 +389,11 @@ class _EnvHandle:
     def __init__(self, runner, i):
         self._r, self._i = runner, i
 
+    # the configuration fields of the reference's per-env object (SingleInversusRLEnv, env_wrappers.py:261-263)
+    opponent_type = property(lambda self: self._r.opponent_type)
+    difficulty = property(lambda self: self._r.difficulty)
+    max_episode_steps = property(lambda self: self._r.max_episode_steps)
+
     @property
     def env(self):
         return _CoreView(self._r.batch, self._i)

@@ -73,6 +73,8 @@ def test_multi_env_runner_matches_reference_seeding_and_shapes():
     g = load("g1_spawn_15x10.npz")
     n = 64                                            # G1 seeds 0..63 == MultiEnvRunner(seed=0) env seeds
     runner = MultiEnvRunner(n, opponent_type="selfplay", seed=0)
+    e0 = runner.envs[0]                               # the per-env object carries the reference's fields (env_wrappers.py:261-266)
+    assert (e0.opponent_type, e0.difficulty, e0.max_episode_steps, e0.step_count, e0.episode_return) == ("selfplay", "easy", 500, 0, 0.0)
     st = runner.batch.get_state()                     # constructor == spawn #0 (core.py:53)
     assert np.array_equal(np.concatenate([st["players"][:, 0, :2], st["players"][:, 1, :2]], 1), g["pos"][:n, 0])
     grid, extra = runner.reset()                      # runner.reset() == spawn #1 of the same streams
