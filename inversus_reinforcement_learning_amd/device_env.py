@@ -172,6 +172,12 @@ class DeviceEnvBatch:
         bits=True (or int32 buffers in `out`): observations as packed bitstrings [N, OW] int32."""
         a1t, a2t = self._as_actions(a1), self._as_actions(a2)
         r = self._alloc_out((), obs, obs_p2, reward64, out, bits)
+        if mask is not None and out is None:
+            # a masked step leaves the slots of the envs that do not step untouched: in buffers allocated here they read as
+            # zeros, not as whatever the allocator handed back (a caller's own `out` keeps its previous contents)
+            for k in StepResult.__slots__:
+                if getattr(r, k) is not None:
+                    getattr(r, k).zero_()
         co = self._c_out(r)
         fl = int(flags) | (L.INV_STEP_AUTO_RESET if auto_reset else 0) | (L.INV_STEP_OBS_BITS if self._is_bits(r) else 0)
         with torch.cuda.device(self.device):

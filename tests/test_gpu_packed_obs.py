@@ -89,7 +89,9 @@ def test_render_bits_rollout_bits_and_masked_step():
     ref = b2.step(a1[0], None, mask=mask, out=None)
     got = as_u32(out.obs)
     assert np.all(got[mask == 0] == 0xFFFFFFFF)
-    assert np.array_equal(got[mask == 1], words_of(ref.obs.cpu().numpy())[mask == 1])
+    refo = ref.obs.cpu().numpy()
+    assert np.array_equal(got[mask == 1], words_of(refo[mask == 1]))
+    assert not refo[mask == 0].any()                 # buffers the masked step allocated itself: zeros where no env stepped
     b1.check(); b2.check()
 
 
