@@ -57,3 +57,19 @@ def test_the_documented_binding_runs_and_matches_the_oracle():
     assert dones > 0                                                       # rounds ended (kills or the 30-step timeout) inside the trace
     with pytest.raises(ValueError):                                        # env_wrappers.py:66: action id outside 0..12
         runner.step(np.full(n, 13, np.uint8))
+
+
+def test_the_readme_usage_lines_run():
+    """README.md, "Use": the four Python lines (import, construct, reset, step) run as written."""
+    import torch
+    with open(os.path.join(ROOT, "README.md")) as fh:
+        doc = fh.read()
+    block = re.findall(r"```python\n(.*?)```", doc[doc.index("## Use"):], flags=re.S)[0]
+    lines = [ln for ln in block.splitlines() if ln.strip() and not ln.startswith(("python ", "    -m "))]
+    assert len(lines) == 4 and lines[0].startswith("from inversus_reinforcement_learning_amd.env_wrappers import MultiEnvRunner")
+    src = "\n".join(lines).replace("num_envs=16384", "num_envs=256")
+    ns = {"actions": torch.randint(0, 13, (256,), device="cuda")}
+    exec(compile(src, "README.md#Use", "exec"), ns)
+    grid, extra = ns["grid"], ns["extra"]
+    assert tuple(grid.shape) == (256, 12, 10, 15) and grid.dtype == torch.float32 and grid.is_cuda and tuple(extra.shape) == (256, 4)
+    assert tuple(ns["rewards"].shape) == (256,) and ns["dones"].dtype == torch.bool and len(ns["infos"]) == 256
