@@ -317,6 +317,13 @@ int  inv_policy_wgrad_to_module(const float *src, const inv_policy_conv_grads *o
 typedef struct { float *gw[4]; float *gb[4]; } inv_policy_ln_grads;
 int  inv_policy_param_grads_all(const inv_policy_grads *grads, const inv_policy_saved *saved, const inv_policy_ln_grads *out,
                                 int32_t slices, int32_t N, void *stream);
+/* ABI 8: the same launch WITHOUT a dy tensor for the top layer.  inv_policy_trunk_bwd accepts grads->dy[3] == NULL and then does not
+ * write it (0.63 GB per 16 384 samples on 15 x 10); this entry point, given dfeat_bf16 (what the backward kernel was given) and
+ * ln_top_packed (inv_policy_bwd_params.ln[3]), recomputes dy_3 = [x^ g + b > 0] * dfeat per element -- the backward kernel's own
+ * expression, so the sums are bit-identical to those from a stored dy[3].  dfeat_bf16 and ln_top_packed: both or neither (neither =
+ * inv_policy_param_grads_all). */
+int  inv_policy_param_grads_all2(const inv_policy_grads *grads, const inv_policy_saved *saved, const inv_policy_ln_grads *out,
+                                 const void *dfeat_bf16, const void *ln_top_packed, int32_t slices, int32_t N, void *stream);
 /* Batch reductions for the LayerNorm gradients of one layer, one pass over dy and xhat (bf16 [N][E], E = 150 * C):
  * partial[s][0][e] = sum dy*xhat, partial[s][1][e] = sum dy over the samples n = s (mod slices); f32 [slices][2][E], every
  * entry written.  Adding the slices gives the LayerNorm weight / bias gradients in [pixel][channel] order. */

@@ -129,6 +129,7 @@ SIGNATURES = {
     "inv_policy_wgrad": (C.c_int, [C.c_int32, _V, _V, _V, _V, C.c_int32, _V]),
     "inv_policy_param_grads": (C.c_int, [_V, _V, _V, C.c_int32, C.c_int32, C.c_int32, _V]),
     "inv_policy_param_grads_all": (C.c_int, [P(InvPolicyGrads), P(InvPolicySaved), P(InvPolicyLnGrads), C.c_int32, C.c_int32, _V]),
+    "inv_policy_param_grads_all2": (C.c_int, [P(InvPolicyGrads), P(InvPolicySaved), P(InvPolicyLnGrads), _V, _V, C.c_int32, C.c_int32, _V]),
     "inv_policy_wgrad_to_module": (C.c_int, [_V, P(InvPolicyConvGrads), _V]),
     "inv_policy_pack_conv": (C.c_int, [_V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _V, _V]),
     "inv_policy_pack_ln": (C.c_int, [_V, _V, C.c_int32, C.c_int32, _V, _V]),

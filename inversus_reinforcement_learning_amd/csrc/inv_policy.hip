@@ -1099,7 +1099,9 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const void *ln_packed, const bf
                 }
                 gc[k] = gk;
 #ifndef POL_BWD_NO_DY
-                reinterpret_cast<bf16x8 *>(dy_n)[q] = dy;
+                // top layer (FROM_GLOBAL): dy = mask * dfeat can be recomputed by the parameter-sum kernel from dfeat, which is in HBM
+                // anyway (ABI 8: grads.dy[3] == NULL) -- 0.63 GB per 16 384 samples that need not be written
+                if (!FROM_GLOBAL || dy_n) reinterpret_cast<bf16x8 *>(dy_n)[q] = dy;
 #endif
                 *reinterpret_cast<bf16x8 *>(tp) = dy;
             }
@@ -1214,7 +1216,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_policy_trunk_bwd(inv_policy_bwd_
         BwdRegs<128> ra;
         BwdRegs<64> rb;
         BwdRegs<32> rc;
-        ln_relu_bwd_rows<128, true>(prm.ln[3], xh3, rs.w, dfeat + sn * 128, reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128,
+        ln_relu_bwd_rows<128, true>(prm.ln[3], xh3, rs.w, dfeat + sn * 128, gr.dy[3] ? reinterpret_cast<bf16 *>(gr.dy[3]) + sn * 128 : nullptr,
                                     reinterpret_cast<bf16 *>(gr.dz[3]) + sn * 128, tile, red, ra, stamp_prev, 3);
         conv_t_to_tile<128, 128, 2, 10, true>(prm.wt[2], tile, lane_i, wave * 2, 0, ra, prm.ln[2], xh2, stamp_prev, 3);
         ln_relu_bwd_rows<128, false>(prm.ln[2], xh2, rs.z, nullptr, reinterpret_cast<bf16 *>(gr.dy[2]) + sn * 128,
@@ -1499,7 +1501,9 @@ __global__ __launch_bounds__(256) void k_wgrad_to_module(WgUnpack u)
 // .grad): no per-slice partial buffers, no reduction / transposition launches afterwards (round 2: 4 launches + 4 torch reductions
 // + 8 layout copies per minibatch).  Item = (layer, pixel, 8 channels); blockIdx.y strides over the samples, four loads of each
 // tensor in flight per thread; 16 f32 atomics per thread at the end (destinations zeroed by the caller).
-struct PgAll { const bf16 *dy[4]; const bf16 *xh[4]; float *gw[4]; float *gb[4]; };
+// dfeat / ln3 (ABI 8, both or neither): the top layer's dy is not read but recomputed as mask * dfeat, mask = [x^ g + b > 0] from the
+// packed fp16 LayerNorm parameters -- the very expression (and rounding: dy is dfeat or 0) of the backward kernel's pass A.
+struct PgAll { const bf16 *dy[4]; const bf16 *xh[4]; float *gw[4]; float *gb[4]; const bf16 *dfeat; const _Float16 *ln3; };
 
 __global__ __launch_bounds__(256) void k_policy_param_grads_all(PgAll a, int N)
 {
@@ -1510,12 +1514,21 @@ __global__ __launch_bounds__(256) void k_policy_param_grads_all(PgAll a, int N)
     const int base = layer == 0 ? 0 : layer == 1 ? I0 : layer == 2 ? I1 : I2;
     const int c8 = layer == 0 ? 4 : layer == 1 ? 8 : 16;                                // 16-byte chunks per pixel
     const int q = it - base, p = q / c8, part = q - p * c8;
-    const bf16 *dyl = layer == 0 ? a.dy[0] : layer == 1 ? a.dy[1] : layer == 2 ? a.dy[2] : a.dy[3];
+    const bool top = layer == 3 && a.dfeat != nullptr;
+    const bf16 *dyl = layer == 0 ? a.dy[0] : layer == 1 ? a.dy[1] : layer == 2 ? a.dy[2] : top ? a.dfeat : a.dy[3];
     const bf16 *xhl = layer == 0 ? a.xh[0] : layer == 1 ? a.xh[1] : layer == 2 ? a.xh[2] : a.xh[3];
     const size_t stride = (size_t)P * c8 * 8;                                           // elements per sample
-    float aw[8], ab[8];
+    float aw[8], ab[8], mg[8], mb[8];                                                   // mg, mb: the item's mask parameters (0, 1 = keep everything)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) aw[j] = ab[j] = 0.0f;
+    for (int j = 0; j < 8; ++j) { aw[j] = ab[j] = 0.0f; mg[j] = 0.0f; mb[j] = 1.0f; }
+    if (top) {
+        const f16x8 l0 = *reinterpret_cast<const f16x8 *>(a.ln3 + (size_t)q * 16), l1 = *reinterpret_cast<const f16x8 *>(a.ln3 + (size_t)q * 16 + 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mg[j] = (float)(j < 4 ? l0[j] : l1[j - 4]);
+            mb[j] = (float)(j < 4 ? l0[4 + j] : l1[j]);
+        }
+    }
     constexpr int U = 4;
     int n = blockIdx.y;
     for (; n + (U - 1) * (int)gridDim.y < N; n += U * gridDim.y) {
@@ -1530,8 +1543,9 @@ __global__ __launch_bounds__(256) void k_policy_param_grads_all(PgAll a, int N)
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float df = (float)d[u][j];
-                aw[j] = fmaf(df, (float)x[u][j], aw[j]);
+                const float xf = (float)x[u][j];
+                const float df = fmaf(xf, mg[j], mb[j]) > 0.0f ? (float)d[u][j] : 0.0f;
+                aw[j] = fmaf(df, xf, aw[j]);
                 ab[j] += df;
             }
     }
@@ -1541,8 +1555,9 @@ __global__ __launch_bounds__(256) void k_policy_param_grads_all(PgAll a, int N)
         const bf16x8 x = *reinterpret_cast<const bf16x8 *>(xhl + o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float df = (float)d[j];
-            aw[j] = fmaf(df, (float)x[j], aw[j]);
+            const float xf = (float)x[j];
+            const float df = fmaf(xf, mg[j], mb[j]) > 0.0f ? (float)d[j] : 0.0f;
+            aw[j] = fmaf(df, xf, aw[j]);
             ab[j] += df;
         }
     }
@@ -2417,7 +2432,7 @@ extern "C" int inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const i
     if (!params || !dfeat_bf16 || !grads || N < 0 || !saved_ok(saved))
         return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_bwd: NULL params / dfeat / grads, an incomplete saved set, or N < 0");
     for (int l = 0; l < 4; ++l)
-        if (!params->ln[l] || !grads->dy[l] || !grads->dz[l] || (l < 3 && !params->wt[l]))
+        if (!params->ln[l] || (!grads->dy[l] && l < 3) || !grads->dz[l] || (l < 3 && !params->wt[l]))      // dy[3] may be NULL (ABI 8)
             return inv_fail(INV_ERR_BAD_ARG, "inv_policy_trunk_bwd: NULL tensor for layer %d", l);
     if (N == 0) return INV_OK;
     hipLaunchKernelGGL(pol::k_policy_trunk_bwd, dim3(trunk_grid(N)), dim3(pol::THREADS), 0, (hipStream_t)stream, *params, *saved,
@@ -2502,13 +2517,26 @@ extern "C" int inv_policy_band_wgrad(int32_t layer, int32_t height, int32_t widt
     }
 }
 
+extern "C" int inv_policy_param_grads_all2(const inv_policy_grads *grads, const inv_policy_saved *saved, const inv_policy_ln_grads *out,
+                                           const void *dfeat_bf16, const void *ln_top_packed, int32_t slices, int32_t N, void *stream);
+
 extern "C" int inv_policy_param_grads_all(const inv_policy_grads *grads, const inv_policy_saved *saved, const inv_policy_ln_grads *out,
                                           int32_t slices, int32_t N, void *stream)
 {
+    return inv_policy_param_grads_all2(grads, saved, out, nullptr, nullptr, slices, N, stream);
+}
+
+extern "C" int inv_policy_param_grads_all2(const inv_policy_grads *grads, const inv_policy_saved *saved, const inv_policy_ln_grads *out,
+                                           const void *dfeat_bf16, const void *ln_top_packed, int32_t slices, int32_t N, void *stream)
+{
     if (!grads || !saved || !out || N < 0 || slices < 1) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_param_grads_all: NULL argument, N < 0 or slices < 1");
+    if ((dfeat_bf16 == nullptr) != (ln_top_packed == nullptr))
+        return inv_fail(INV_ERR_BAD_ARG, "inv_policy_param_grads_all2: dfeat and the top layer's packed LayerNorm parameters come together");
     pol::PgAll a;
+    a.dfeat = reinterpret_cast<const pol::bf16 *>(dfeat_bf16);
+    a.ln3 = reinterpret_cast<const _Float16 *>(ln_top_packed);
     for (int l = 0; l < 4; ++l) {
-        if (!grads->dy[l] || !saved->xhat[l] || !out->gw[l] || !out->gb[l]) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_param_grads_all: NULL tensor for layer %d", l);
+        if ((!grads->dy[l] && !(l == 3 && dfeat_bf16)) || !saved->xhat[l] || !out->gw[l] || !out->gb[l]) return inv_fail(INV_ERR_BAD_ARG, "inv_policy_param_grads_all: NULL tensor for layer %d", l);
         a.dy[l] = reinterpret_cast<const pol::bf16 *>(grads->dy[l]); a.xh[l] = reinterpret_cast<const pol::bf16 *>(saved->xhat[l]);
         a.gw[l] = out->gw[l]; a.gb[l] = out->gb[l];
     }

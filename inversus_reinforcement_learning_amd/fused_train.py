@@ -139,7 +139,9 @@ class _TrunkTrainFn(torch.autograd.Function):
         xhat, act, lns, ws = sv[2:6], sv[6:9], sv[9:13], sv[13:17]
         dev, n = obs.device, obs.shape[0]
         dfeat = dfeat.contiguous().to(torch.bfloat16)
-        dy = [torch.empty_like(t) for t in xhat]
+        # no dy tensor for the top layer (ABI 8): the parameter-sum kernel recomputes it from dfeat; INVERSUS_TOP_DY=1 keeps the old path
+        top_dy = os.environ.get("INVERSUS_TOP_DY", "0") == "1"
+        dy = [torch.empty_like(t) if (i < 3 or top_dy) else None for i, t in enumerate(xhat)]
         dz = [torch.empty_like(t) for t in xhat]
         bp, keep = L.InvPolicyBwdParams(), []
         for i in range(1, 4):                       # Wt[ci][8 - tap][co] = W[co][ci][tap], packed as a conv with Cin = Cout_i
@@ -151,7 +153,7 @@ class _TrunkTrainFn(torch.autograd.Function):
         saved, grads = L.InvPolicySaved(), L.InvPolicyGrads()
         for i in range(4):
             saved.xhat[i] = xhat[i].data_ptr()
-            grads.dy[i] = dy[i].data_ptr()
+            grads.dy[i] = dy[i].data_ptr() if dy[i] is not None else None
             grads.dz[i] = dz[i].data_ptr()
         for i in range(3):
             saved.act[i] = act[i].data_ptr()
@@ -193,7 +195,8 @@ class _TrunkTrainFn(torch.autograd.Function):
             sv_k, gr_k = L.InvPolicySaved(), L.InvPolicyGrads()
             for i in range(4):
                 off = lo * 150 * _COUT[i] * 2
-                sv_k.xhat[i], gr_k.dy[i], gr_k.dz[i] = saved.xhat[i] + off, grads.dy[i] + off, grads.dz[i] + off
+                sv_k.xhat[i], gr_k.dz[i] = saved.xhat[i] + off, grads.dz[i] + off
+                gr_k.dy[i] = grads.dy[i] + off if grads.dy[i] else None
             for i in range(3):
                 sv_k.act[i] = saved.act[i] + lo * 150 * _COUT[i] * 2
             sv_k.rstd = saved.rstd + lo * 16
@@ -205,8 +208,11 @@ class _TrunkTrainFn(torch.autograd.Function):
                 side.wait_stream(main)
             with torch.cuda.stream(side):
                 with torch.cuda.device(dev):
-                    rc = lib.inv_policy_param_grads_all(C.byref(gr_k), C.byref(sv_k), C.byref(lng), _PG_SLICES if m >= 8192 else max(16, _PG_SLICES // 2), m,
-                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                    rc = lib.inv_policy_param_grads_all2(C.byref(gr_k), C.byref(sv_k), C.byref(lng),
+                                                         None if top_dy else C.c_void_p(dfeat.data_ptr() + lo * 19200 * 2),
+                                                         None if top_dy else C.c_void_p(lns[3].data_ptr()),
+                                                         _PG_SLICES if m >= 8192 else max(16, _PG_SLICES // 2), m,
+                                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
                 L.raise_for(rc, lib)
             lo += m
         if mid is not None:

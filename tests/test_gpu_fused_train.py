@@ -340,3 +340,70 @@ def test_graph_captured_minibatches_give_the_eager_minibatches_gradients():
     assert float(f0.norm()) > 0
     for a, b in zip(g0, g1):
         assert float((a.double() - b.double()).norm()) <= 1e-4 * float(a.double().norm()) + 1e-9, (tuple(a.shape), float((a - b).norm() / a.norm()))
+
+
+@pytest.mark.parametrize("n", [1, 333, 4096])
+def test_top_layer_sums_without_a_dy_tensor_are_bitwise_the_sums_from_the_stored_dy(n):
+    """ABI 8: inv_policy_trunk_bwd with grads.dy[3] == NULL writes no dy for the top layer, inv_policy_param_grads_all2 recomputes it
+    as [x^ g + b > 0] * dfeat.  With ONE sample slice every output element receives exactly one atomic add onto zero, so the four
+    layers' sums of both routes can be compared bit for bit; dz does not depend on whether dy[3] is stored."""
+    import ctypes as C
+    import torch
+    from inversus_reinforcement_learning_amd import _lib as L
+    from inversus_reinforcement_learning_amd import fused_train as FT
+    lib = L.load()
+    pol = _policy(3).train()
+    ft = FT.FusedTrainPolicy(pol)
+    gf, _, _ = _obs(n, 5)
+    feat = ft.features(gf)
+    sv = feat.grad_fn.saved_tensors
+    obs, rstd = sv[0], sv[1]
+    xhat, act, lns, ws = sv[2:6], sv[6:9], sv[9:13], sv[13:17]
+    df = (torch.randn_like(feat.float()) * 0.01).to(torch.bfloat16)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bp, keep = L.InvPolicyBwdParams(), []
+    for i in range(1, 4):
+        pk = FT.pack_conv(ws[i], FT._COUT[i], transposed=True); keep.append(pk); bp.wt[i - 1] = pk.data_ptr()
+    for i in range(4):
+        bp.ln[i] = lns[i].data_ptr()
+    saved = L.InvPolicySaved()
+    for i in range(4):
+        saved.xhat[i] = xhat[i].data_ptr()
+    for i in range(3):
+        saved.act[i] = act[i].data_ptr()
+    saved.rstd = rstd.data_ptr()
+    res = []
+    for stored in (True, False):
+        dy = [torch.full_like(x, 7.0) if (i < 3 or stored) else None for i, x in enumerate(xhat)]
+        dz = [torch.full_like(x, 7.0) for x in xhat]
+        grads = L.InvPolicyGrads()
+        for i in range(4):
+            grads.dy[i] = dy[i].data_ptr() if dy[i] is not None else None
+            grads.dz[i] = dz[i].data_ptr()
+        L.raise_for(lib.inv_policy_trunk_bwd(C.byref(bp), C.byref(saved), C.c_void_p(df.data_ptr()), C.byref(grads), n, st), lib)
+        lng = L.InvPolicyLnGrads()
+        gw = [torch.zeros(c, 10, 15, device="cuda") for c in FT._COUT]
+        gb = [torch.zeros(c, 10, 15, device="cuda") for c in FT._COUT]
+        for i in range(4):
+            lng.gw[i], lng.gb[i] = gw[i].data_ptr(), gb[i].data_ptr()
+        if stored:
+            L.raise_for(lib.inv_policy_param_grads_all(C.byref(grads), C.byref(saved), C.byref(lng), 1, n, st), lib)
+        else:
+            L.raise_for(lib.inv_policy_param_grads_all2(C.byref(grads), C.byref(saved), C.byref(lng), C.c_void_p(df.data_ptr()),
+                                                         C.c_void_p(lns[3].data_ptr()), 1, n, st), lib)
+        torch.cuda.synchronize()
+        res.append((dz, gw, gb, dy))
+    (dz_a, gw_a, gb_a, dy_a), (dz_b, gw_b, gb_b, _) = res
+    for i in range(4):
+        assert torch.equal(dz_a[i], dz_b[i]), i
+        assert torch.equal(gw_a[i], gw_b[i]) and torch.equal(gb_a[i], gb_b[i]), i
+    assert float(gw_a[3].abs().sum()) > 0 and float(gb_a[3].abs().sum()) > 0
+    # the stored dy of the top layer IS the masked dfeat (what the recomputation assumes)
+    keepm = dy_a[3] != 0
+    assert torch.equal(dy_a[3][keepm], df.reshape_as(dy_a[3])[keepm]) and 0.2 < float(keepm.float().mean()) < 0.9
+    # argument checks: dfeat and the packed parameters come together; without them dy[3] is required
+    grads = L.InvPolicyGrads()
+    for i in range(3):
+        grads.dy[i] = dy_a[i].data_ptr()
+    assert lib.inv_policy_param_grads_all2(C.byref(grads), C.byref(saved), C.byref(lng), C.c_void_p(df.data_ptr()), None, 1, n, st) == L.INV_ERR_BAD_ARG
+    assert lib.inv_policy_param_grads_all(C.byref(grads), C.byref(saved), C.byref(lng), 1, n, st) == L.INV_ERR_BAD_ARG
