@@ -300,6 +300,8 @@ typedef struct { void *dy[4]; void *dz[4]; } inv_policy_grads;
  * BIT FOR BIT (tests/test_gpu_fused_train.py); it runs the inference kernel's epilogue, at the inference kernel's speed. */
 int  inv_policy_trunk_train_fwd(const inv_policy_params *params, const void *obs, int32_t obs_is_bits, void *feat_bf16,
                                 const inv_policy_saved *saved, int32_t N, void *stream);
+/* grads->dy[3] may be NULL (ABI 8): the top layer's dy = [x^ g + b > 0] * dfeat is then not written, and
+ * inv_policy_param_grads_all2 recomputes it from dfeat (every other member is required). */
 int  inv_policy_trunk_bwd(const inv_policy_bwd_params *params, const inv_policy_saved *saved, const void *dfeat_bf16,
                           const inv_policy_grads *grads, int32_t N, void *stream);
 /* Weight (and bias) gradient of convolution `layer` (0..3): dw[co][tap][ci] += sum_n sum_p dz[n][p][co] * x[n][p + tap][ci],
